@@ -1,0 +1,121 @@
+"""The oracle against the known-answer values that SURVEY.md section 8(c) recorded from the REAL, complete
+reference build (LumaEncoder::setChannels included).  CPU only.  Digests are the survey probe's FNV-1a-64
+variant (offset basis 1469598103934665603, see oracle/luma_oracle.h)."""
+import numpy as np
+import pytest
+
+
+def q(o, name):
+    cfg = {"pq11": (o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005),
+           "pq10": (o.PTF_PQ, 10, o.CS_YCBCR, 10, 1000.0, 0.01),
+           "log12": (o.PTF_LOG, 12, o.CS_LUV, 8, 1e4, 0.005),
+           "lin12": (o.PTF_LINEAR, 12, o.CS_LUV, 8, 1e4, 0.005),
+           "pq8": (o.PTF_PQ, 8, o.CS_LUV, 8, 1e4, 0.005)}[name]
+    return o.Oracle(*cfg)
+
+
+@pytest.mark.parametrize("name,n,digest,probes", [
+    ("pq11", 2048, "13a2e8d75a2f55fd", {0: 0.0, 1: 1.24098524e-05, 1024: 92.5402908, 2047: 9999.74902}),
+    ("pq10", 1024, "90519baed0c779eb", {1: 4.05279025e-06, 512: 9.27665043, 1023: 999.974915}),
+    ("log12", 4096, "cd09726f0cc6313b", {0: 0.00500000082, 2048: 7.08361197, 4095: 10000.0}),
+    ("lin12", 4096, "a24a90d2b5eff995", {}),
+    ("pq8", 256, "91c04c43794c0a29", {}),
+])
+def test_lut_pins(oracle_mod, name, n, digest, probes):
+    m = q(oracle_mod, name).mapping
+    assert m.size == n
+    assert oracle_mod.survey_digest(m) == digest
+    for i, v in probes.items():
+        assert m[i] == np.float32(v)
+    assert np.all(np.diff(m) > 0)  # strictly increasing (survey probe: nonmono=0, dups=0)
+
+
+def test_table_lut_pins(oracle_mod):
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lumahdrv_amd", "data")
+    for nm, ptf, dg in (("jnd_hdrvdp", oracle_mod.PTF_JND_HDRVDP, "774e63695ee9beb4"),
+                        ("psi", oracle_mod.PTF_PSI, "c25cb4cde5b36494")):
+        t = np.fromfile(os.path.join(d, "ptf_%s_11.f32" % nm), dtype="<f4")
+        m = oracle_mod.Oracle(ptf, 11, oracle_mod.CS_LUV, 8, 1e4, 0.005, table=t).mapping
+        assert oracle_mod.survey_digest(m) == dg
+
+
+VALS = [0, 1e-4, 0.005, 0.01, 1, 100, 1000, 9999, 1e4, 1e8]
+
+
+@pytest.mark.parametrize("name,codes", [
+    ("pq11", [0, 3, 31, 44, 307, 1040, 1539, 2047, 2047, 2047]),
+    ("log12", [0, 0, 0, 196, 1495, 2795, 3445, 4095, 4095, 4095]),
+    ("pq10", [0, 6, 47, 64, 307, 769, 1023, 1023, 1023, 1023]),
+])
+def test_quantize_pins(oracle_mod, name, codes):
+    qq = q(oracle_mod, name)
+    assert [int(qq.quantize(v, 0)) for v in VALS] == codes
+
+
+def const_frame(rgb, h=2, w=2):
+    f = np.empty((3, h, w), dtype=np.float32)
+    for c in range(3):
+        f[c] = np.float32(rgb[c])
+    return f
+
+
+def yuv(planes):
+    y = planes[0].view("<u2")[0, 0]
+    return int(y), int(planes[1].view("<u2")[0, 0]), int(planes[2].view("<u2")[0, 0])
+
+
+@pytest.mark.parametrize("rgb,bits,codes", [
+    ((1, 1, 1), ("3f800000", "3ea2dc5f", "3f40c44a"), (307, 81, 192)),
+    ((100, 100, 100), ("42c80000", "3ea2dc5f", "3f40c448"), (1040, 81, 192)),
+    ((10000, 0, 0), None, (1707, 185, 214)),
+    ((0, 10000, 0), None, (1975, 51, 231)),
+    ((0, 0, 10000), None, (1466, 72, 65)),
+    ((0, 0, 0), ("38d1b717", "3ead4eff", "3f42f8de"), (3, 86, 194)),
+    ((1e-6, 1e-6, 1e-6), ("38d1b717", "3ead4eff", "3f42f8de"), (3, 86, 194)),
+    ((0.5, 20, 3), None, (676, 53, 222)),
+    ((-5, 2, 1), None, (229, 0, 164)),
+    ((np.nan, 1, 1), None, (2047, 255, 255)),
+    ((np.inf, 1, 1), None, (2047, 86, 194)),
+    ((65504, 65504, 65504), None, (2047, 81, 192)),
+])
+def test_constant_colour_pins_luv(oracle_mod, rgb, bits, codes):
+    qq = q(oracle_mod, "pq11")
+    f = const_frame(rgb)
+    planes, _, _ = qq.encode(f, 1.0, 2)
+    if bits:
+        assert tuple("%08x" % v for v in f[:, 0, 0].view(np.uint32)) == bits
+    assert yuv(planes) == codes
+
+
+@pytest.mark.parametrize("rgb,codes", [
+    ((1, 1, 1), (573, 514, 514)), ((0.5, 20, 3), (755, 470, 344)), ((0, 0, 0), (64, 514, 514)),
+    ((10000, 0, 0), (403, 329, 1023)), ((np.nan, 1, 1), (1023, 1023, 1023)),
+])
+def test_constant_colour_pins_ycbcr(oracle_mod, rgb, codes):
+    qq = q(oracle_mod, "pq10")
+    planes, _, _ = qq.encode(const_frame(rgb), 20.0, 2)
+    assert yuv(planes) == codes
+
+
+@pytest.mark.parametrize("w,h,d", [
+    (1280, 720, ("7881e7d4ba964843", "db8ff401614db503", "e0ff09731298e8f6", "4c410839cf4228cc", "28868357f4a5e5e5")),
+    (1920, 1080, ("f86dee2dca99b95b", "a3e03753f3d1fe44", "ccbc4f62ce2708ab", "efe7b8578cae8ef2", "fe374dc25dde5096")),
+])
+def test_testframe_plane_digests(oracle_mod, w, h, d):
+    """test_simple_enc parameters (PQ 11-bit, Lu'v', 8-bit colour, profile 2) on ExrInterface::testFrame:
+    input floats / Lu'v' floats / Y / U / V plane digests from the complete reference encoder."""
+    o = oracle_mod
+    qq = q(o, "pq11")
+    f = o.test_frame(w, h)
+    assert o.survey_digest(f) == d[0]
+    planes, strides, avg = qq.encode(f, 1.0, 2)
+    assert o.survey_digest(f) == d[1]
+    assert o.survey_digest(o.packed_rows(planes[0], 2 * w)) == d[2]
+    assert o.survey_digest(o.packed_rows(planes[1], w)) == d[3]
+    assert o.survey_digest(o.packed_rows(planes[2], w)) == d[4]
+    assert avg > 1.0
+    # multi-threaded banding must not change a byte
+    f2 = o.test_frame(w, h)
+    planes2, _, _ = qq.encode(f2, 1.0, 2, threads=4)
+    assert all(np.array_equal(a, b) for a, b in zip(planes, planes2))
