@@ -1,0 +1,156 @@
+/*
+ * lumahip.h -- C ABI of the MI355X-native Luma HDRv quantize / dequantize hot path.
+ *
+ * This is the drop-in boundary.  The reference (gabrieleilertsen/lumahdrv v1.0.0) has no FFI layer: its
+ * boundary is the C++ class API LumaQuantizer / LumaEncoder::encode(LumaFrame*) / LumaDecoder::decode().
+ * The C++ facade in include/luma/ keeps that class surface and is implemented on top of the functions
+ * below; every function names the reference interface it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only -- no HIP, torch or C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns LUMAHIP_OK (0) or an error code; nothing throws across the boundary;
+ *     lumahip_last_error(ctx) returns a human-readable message for the last failure on that context;
+ *   - frames are the reference's LumaFrame layout (include/luma/luma_frame.h:51-90): planar fp32,
+ *     channel c at base + c*h*w, rows of w floats, no padding;
+ *   - coded planes are the three Y/U/V planes of a vpx_image_t as the reference fills and reads them
+ *     (src/luma_encoder.cpp:260-317, src/luma_decoder.cpp:205-240): planes[p] + y*stride[p] + x*bps,
+ *     16-bit samples little-endian; `profile` is the VP9 profile that selects the layout exactly as
+ *     src/luma_encoder.cpp:121-128 does: 0 = 4:2:0 8-bit, 1 = 4:4:4 8-bit, 2 = 4:2:0 16-bit,
+ *     3 = 4:4:4 16-bit;
+ *   - width and height must be even and non-zero (src/luma_encoder.cpp:118-119);
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe; distinct contexts are
+ *     independent.  "_host" entry points take host pointers and return when the results are in host
+ *     memory; "_device" entry points take device pointers, enqueue on the context's stream and return
+ *     immediately (lumahip_sync waits).
+ *   - there is no CPU fallback: without a HIP device every entry point fails with LUMAHIP_ERR_HIP.
+ */
+#ifndef LUMAHIP_H
+#define LUMAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUMAHIP_ABI_VERSION 1
+
+enum lumahip_status {
+    LUMAHIP_OK = 0,
+    LUMAHIP_ERR_ARG = 1,         /* bad argument (odd size, null pointer, unknown enum, ...) */
+    LUMAHIP_ERR_HIP = 2,         /* a HIP runtime call failed / no device */
+    LUMAHIP_ERR_STATE = 3,       /* quantizer not set */
+    LUMAHIP_ERR_UNSUPPORTED = 4  /* e.g. unknown colour space: the reference's transformColorSpace()==false */
+};
+
+/* numeric values are serialised by the reference into MKV attachments 432 / 433
+ * (include/luma/luma_quantizer.h:95-96, src/luma_encoder.cpp:86-92) */
+enum lumahip_ptf { LUMAHIP_PTF_PSI = 0, LUMAHIP_PTF_PQ = 1, LUMAHIP_PTF_LOG = 2, LUMAHIP_PTF_JND_HDRVDP = 3,
+                   LUMAHIP_PTF_LINEAR = 4 };
+enum lumahip_colorspace { LUMAHIP_CS_LUV = 0, LUMAHIP_CS_RGB = 1, LUMAHIP_CS_YCBCR = 2, LUMAHIP_CS_XYZ = 3 };
+
+typedef struct lumahip_ctx lumahip_ctx;
+
+/* ---- life cycle -------------------------------------------------------------------------------- */
+
+int lumahip_abi_version(void);
+int lumahip_device_count(int *count);
+/* device = HIP ordinal, or -1 for the calling thread's current device */
+int lumahip_create(lumahip_ctx **out, int device);
+void lumahip_destroy(lumahip_ctx *ctx);
+const char *lumahip_last_error(const lumahip_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead of the context's own
+ * stream; NULL restores the context's stream. */
+int lumahip_set_stream(lumahip_ctx *ctx, void *hip_stream);
+int lumahip_sync(lumahip_ctx *ctx);
+
+/* ---- quantizer --------------------------------------------------------------------------------- */
+
+/* Replaces LumaQuantizer::setQuantizer (src/luma_quantizer.cpp:172-212) for the device side.  The host
+ * facade builds the LUT exactly as the reference does (libm powf/log10f or the PSI/HDR-VDP tables) and,
+ * on the decoder, overwrites its first getSize() entries with MKV attachment 434
+ * (src/luma_decoder.cpp:121-122); the FINAL table of 2^bitdepth floats is handed over here.
+ * bitdepth 1..16, bitdepthC 1..16.  The call uploads the LUT and builds the search index. */
+int lumahip_set_quantizer(lumahip_ctx *ctx, int ptf, unsigned bitdepth, int colorspace, unsigned bitdepthC,
+                          float maxLum, float minLum, const float *lut_host, size_t lut_len);
+
+/* Host-only helper: builds the 2^bitdepth-entry table exactly as LumaQuantizer::setQuantizer does
+ * (src/luma_quantizer.cpp:114-169,172-212) -- host libm powf / log10f for PQ / LOG, Lmax*i/maxVal for
+ * LINEAR, the captured PSI / JND-HDR-VDP data tables (lumahdrv_amd/data, or $LUMAHIP_DATA_DIR) otherwise.
+ * Needs no GPU and no context.  LUMAHIP_ERR_UNSUPPORTED for PSI/HDR-VDP deeper than 12 bits (the
+ * reference reads out of bounds there), LUMAHIP_ERR_STATE if a data table cannot be read. */
+int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, float *lut_out, size_t lut_len);
+
+/* introspection of the search index built for the current LUT (tests):
+ * info[0] = mode (0 = literal bisection, LUT in LDS; 1 = bucketed search, LUT in LDS;
+ *                 2 = literal bisection, LUT read from global memory (bitdepth > 12)),
+ * info[1] = mantissa bits of the bucket key, info[2] = number of buckets, info[3] = refinement steps,
+ * info[4] = LDS bytes per workgroup */
+int lumahip_quantizer_info(const lumahip_ctx *ctx, int info[5]);
+
+/* ---- host entry points (drop-in: H2D, kernel, D2H, synchronous) -------------------------------- */
+
+/* Replaces LumaEncoder::encode(LumaFrame*) minus run(), i.e. transformColorSpace(frame,true,sc) +
+ * setChannels(frame) (include/luma/luma_encoder.h:142-148, src/luma_encoder.cpp:196-201,260-317), as ONE
+ * fused kernel.  `rgb` is not modified.  If `transformed_out` is non-NULL it receives the 3*w*h floats
+ * the reference leaves in the caller's frame (its in-place side effect).
+ * `mean_lum` (nullable) receives the plane-0 average the reference computes for its
+ * "mean luminance <= 1" warning (src/luma_encoder.cpp:313-316). */
+int lumahip_encode_frame_host(lumahip_ctx *ctx, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                              unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                              float *transformed_out);
+
+/* Replaces LumaDecoder::decode() minus run(), i.e. getVpxChannels() + transformColorSpace(frame,false,sc)
+ * (include/luma/luma_decoder.h:143-161, src/luma_decoder.cpp:205-240) as one fused kernel. */
+int lumahip_decode_frame_host(lumahip_ctx *ctx, const unsigned char *const planes[3], const int stride[3],
+                              unsigned w, unsigned h, int profile, float sc, float *rgb_out);
+
+/* Replaces LumaQuantizer::transformColorSpace(LumaFrame*, bool toCs, float sc)
+ * (src/luma_quantizer.cpp:267-482): in place on a host frame.  Returns LUMAHIP_ERR_UNSUPPORTED where the
+ * reference returns false. */
+int lumahip_transform_color_space_host(lumahip_ctx *ctx, float *frame, unsigned w, unsigned h, int toCs, float sc);
+
+/* LumaQuantizer::quantize / dequantize (src/luma_quantizer.cpp:215-264) over arrays; `ch` as in the
+ * reference (0 = LUT channel; 1,2 = colour channels unless the colour space is RGB/XYZ). */
+int lumahip_quantize_array_host(lumahip_ctx *ctx, const float *in, float *out, size_t n, unsigned ch);
+int lumahip_dequantize_array_host(lumahip_ctx *ctx, const float *in, float *out, size_t n, unsigned ch);
+
+/* ---- device entry points (batched, asynchronous on the context's stream) ----------------------- */
+
+/* nframes frames, frame f at rgb_dev + f*frame_stride floats (LumaFrame layout each); plane p of frame f
+ * at planes_dev[p] + f*plane_frame_stride[p] bytes.  stats_dev (nullable) receives per frame
+ * {sum, min, max} of transformed channel 0 as 3 floats (zero-initialised by the call).
+ * One launch covers all frames. */
+int lumahip_encode_frames_device(lumahip_ctx *ctx, const float *rgb_dev, size_t frame_stride, unsigned nframes,
+                                 unsigned w, unsigned h, float sc, int profile, unsigned char *const planes_dev[3],
+                                 const int stride[3], const size_t plane_frame_stride[3], float *stats_dev);
+int lumahip_decode_frames_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                 const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
+                                 int profile, float sc, float *rgb_dev, size_t frame_stride);
+int lumahip_transform_color_space_device(lumahip_ctx *ctx, float *frames_dev, size_t frame_stride, unsigned nframes,
+                                         unsigned w, unsigned h, int toCs, float sc);
+
+/* Synthetic benchmark input, generated on the device by the integer-only recipe of SURVEY.md 8(d)
+ * (identical to the oracle's lo_synth_frame): frame index first_frame + f at dst_dev + f*frame_stride. */
+int lumahip_synth_frames_device(lumahip_ctx *ctx, float *dst_dev, size_t frame_stride, unsigned nframes,
+                                unsigned w, unsigned h, uint64_t seed, uint64_t first_frame);
+
+/* Timing helper for benchmarks: runs `iters` encode (dir=0) or decode (dir=1) launches of the same
+ * arguments back to back on the context's stream between two hipEvents and returns the average
+ * kernel-launch duration in milliseconds (events are recorded on the stream the kernels run on). */
+int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb_dev, size_t frame_stride,
+                          unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                          unsigned char *const planes_dev[3], const int stride[3],
+                          const size_t plane_frame_stride[3], float *avg_ms);
+
+/* ---- device memory helpers (for hosts without their own allocator, e.g. the C++ facade) -------- */
+int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
+int lumahip_free(lumahip_ctx *ctx, void *dev_ptr);
+int lumahip_memcpy_h2d(lumahip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int lumahip_memcpy_d2h(lumahip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUMAHIP_H */

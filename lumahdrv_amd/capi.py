@@ -1,0 +1,261 @@
+"""ctypes binding of include/lumahip.h (the C ABI of liblumahip.so).  Nothing here computes pixels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(HERE, "lib", "liblumahip.so")
+
+# include/luma/luma_quantizer.h:95-96 (values are serialised in the stream metadata)
+PTF_PSI, PTF_PQ, PTF_LOG, PTF_JND_HDRVDP, PTF_LINEAR = range(5)
+CS_LUV, CS_RGB, CS_YCBCR, CS_XYZ = range(4)
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
+
+SYMBOLS = [
+    "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
+    "lumahip_set_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
+    "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_transform_color_space_host",
+    "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_encode_frames_device",
+    "lumahip_decode_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
+    "lumahip_time_launches", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+]
+
+
+class LumaHipError(RuntimeError):
+    """Counterpart of the reference's LumaException (include/luma/luma_exception.h:53-71)."""
+
+    def __init__(self, code, msg):
+        super().__init__("lumahip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def build_library(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into lumahdrv_amd/lib/liblumahip.so (hipcc cross-compiles
+    without a GPU)."""
+    cmd = ["make", "-s", "-C", os.path.join(HERE, "csrc")]
+    if force:
+        subprocess.run(cmd + ["clean"], check=True)
+    subprocess.run(cmd, check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load liblumahip.so.  torch, when installed, is imported FIRST: its wheel bundles its own
+    libamdhip64.so (same SONAME as /opt/rocm's), and the process must end up with exactly one HIP
+    runtime so that device pointers from torch tensors are valid in our launches."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise LumaHipError(ERR_STATE, "%s not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(there is no CPU fallback)" % _LIB_PATH)
+    if "torch" not in sys.modules and not os.environ.get("LUMAHIP_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u, i, f, sz = C.c_void_p, C.c_uint, C.c_int, C.c_float, C.c_size_t
+    pp3 = C.POINTER(C.c_void_p)
+    ip3 = C.POINTER(C.c_int)
+    sp3 = C.POINTER(C.c_size_t)
+    L.lumahip_abi_version.restype = i
+    L.lumahip_device_count.argtypes = [C.POINTER(i)]
+    L.lumahip_create.argtypes = [C.POINTER(vp), i]
+    L.lumahip_destroy.argtypes = [vp]
+    L.lumahip_destroy.restype = None
+    L.lumahip_last_error.argtypes = [vp]
+    L.lumahip_last_error.restype = C.c_char_p
+    L.lumahip_set_stream.argtypes = [vp, vp]
+    L.lumahip_sync.argtypes = [vp]
+    L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
+    L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
+    L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
+    L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
+    L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
+    L.lumahip_transform_color_space_host.argtypes = [vp, vp, u, u, i, f]
+    L.lumahip_quantize_array_host.argtypes = [vp, vp, vp, sz, u]
+    L.lumahip_dequantize_array_host.argtypes = [vp, vp, vp, sz, u]
+    L.lumahip_encode_frames_device.argtypes = [vp, vp, sz, u, u, u, f, i, pp3, ip3, sp3, vp]
+    L.lumahip_decode_frames_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, vp, sz]
+    L.lumahip_transform_color_space_device.argtypes = [vp, vp, sz, u, u, u, i, f]
+    L.lumahip_synth_frames_device.argtypes = [vp, vp, sz, u, u, u, C.c_uint64, C.c_uint64]
+    L.lumahip_time_launches.argtypes = [vp, i, i, vp, sz, u, u, u, f, i, pp3, ip3, sp3, C.POINTER(f)]
+    L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
+    L.lumahip_free.argtypes = [vp, vp]
+    L.lumahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.lumahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    _lib = L
+    return L
+
+
+def plane_geometry(w: int, h: int, profile: int, align: int = 32):
+    """(widths, heights, strides-in-bytes, bytes-per-sample) of the Y/U/V planes as
+    vpx_img_alloc(fmt(profile), w, h, 32) lays them out (src/luma_encoder.cpp:121-128)."""
+    sub = profile in (0, 2)
+    bps = 2 if profile > 1 else 1
+    s0 = (w + align - 1) // align * align * bps
+    cw, ch = ((w + 1) // 2, (h + 1) // 2) if sub else (w, h)
+    s1 = s0 // 2 if sub else s0
+    return (w, cw, cw), (h, ch, ch), (s0, s1, s1), bps
+
+
+def build_lut(ptf: int, bitdepth: int, max_lum: float = 1e4, min_lum: float = 0.005) -> np.ndarray:
+    """The transfer-function table of LumaQuantizer::setQuantizer, built by the library's host code with the
+    host libm exactly as the reference does (no GPU needed)."""
+    out = np.empty(1 << bitdepth, dtype=np.float32)
+    rc = lib().lumahip_build_lut(ptf, bitdepth, max_lum, min_lum, out.ctypes.data, out.size)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_build_lut(ptf=%d, bitdepth=%d) failed" % (ptf, bitdepth))
+    return out
+
+
+def _arr3(ctype, vals):
+    return (ctype * 3)(*vals)
+
+
+class Context:
+    """One GPU, one stream, one quantizer configuration (lumahip_ctx)."""
+
+    def __init__(self, device: int = -1):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.lumahip_create(C.byref(h), device)
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_create failed: no usable HIP device (there is no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lumahip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise LumaHipError(rc, self.L.lumahip_last_error(self.h).decode())
+
+    # ---- configuration
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self.L.lumahip_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        self._chk(self.L.lumahip_sync(self.h))
+
+    def set_quantizer(self, ptf, bitdepth, cs, bitdepthC, max_lum, min_lum, lut: np.ndarray):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        self._chk(self.L.lumahip_set_quantizer(self.h, ptf, bitdepth, cs, bitdepthC, max_lum, min_lum,
+                                               lut.ctypes.data, lut.size))
+
+    def quantizer_info(self):
+        a = (C.c_int * 5)()
+        self._chk(self.L.lumahip_quantizer_info(self.h, a))
+        return dict(mode=a[0], mant_bits=a[1], buckets=a[2], steps=a[3], lds_bytes=a[4])
+
+    # ---- host entry points (numpy)
+    def encode_frame(self, rgb: np.ndarray, sc=1.0, profile=2, align=32, want_transformed=False, strides=None):
+        """rgb: (3,h,w) float32 (LumaFrame layout).  Returns (planes, strides, mean_lum[, transformed])."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        _, h, w = rgb.shape
+        _, hs, st, _ = plane_geometry(w, h, profile, align)
+        if strides is not None:
+            st = tuple(strides)
+        planes = [np.zeros((hs[p], st[p]), dtype=np.uint8) for p in range(3)]
+        mean = C.c_float(0)
+        tr = np.empty_like(rgb) if want_transformed else None
+        self._chk(self.L.lumahip_encode_frame_host(self.h, rgb.ctypes.data, w, h, sc, profile,
+                                                   _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
+                                                   _arr3(C.c_int, st), C.byref(mean),
+                                                   tr.ctypes.data if tr is not None else None))
+        if want_transformed:
+            return planes, st, float(mean.value), tr
+        return planes, st, float(mean.value)
+
+    def decode_frame(self, planes, strides, w, h, sc=1.0, profile=2) -> np.ndarray:
+        planes = [np.ascontiguousarray(p) for p in planes]
+        out = np.empty((3, h, w), dtype=np.float32)
+        self._chk(self.L.lumahip_decode_frame_host(self.h, _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
+                                                   _arr3(C.c_int, strides), w, h, profile, sc, out.ctypes.data))
+        return out
+
+    def transform_color_space(self, frame: np.ndarray, to_cs: bool, sc=1.0) -> np.ndarray:
+        assert frame.dtype == np.float32 and frame.flags.c_contiguous and frame.shape[0] == 3
+        self._chk(self.L.lumahip_transform_color_space_host(self.h, frame.ctypes.data, frame.shape[2], frame.shape[1],
+                                                            int(bool(to_cs)), sc))
+        return frame
+
+    def quantize_array(self, a, ch=0) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        self._chk(self.L.lumahip_quantize_array_host(self.h, a.ctypes.data, out.ctypes.data, a.size, ch))
+        return out
+
+    def dequantize_array(self, a, ch=0) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        self._chk(self.L.lumahip_dequantize_array_host(self.h, a.ctypes.data, out.ctypes.data, a.size, ch))
+        return out
+
+    # ---- device entry points (raw device pointers, e.g. torch.Tensor.data_ptr())
+    def encode_frames_device(self, rgb_ptr, frame_stride, nframes, w, h, sc, profile, plane_ptrs, strides,
+                             plane_frame_strides, stats_ptr=None):
+        self._chk(self.L.lumahip_encode_frames_device(self.h, rgb_ptr, frame_stride, nframes, w, h, sc, profile,
+                                                      _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                      _arr3(C.c_size_t, plane_frame_strides), stats_ptr))
+
+    def decode_frames_device(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, profile, sc, rgb_ptr,
+                             frame_stride):
+        self._chk(self.L.lumahip_decode_frames_device(self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                      _arr3(C.c_size_t, plane_frame_strides), nframes, w, h, profile,
+                                                      sc, rgb_ptr, frame_stride))
+
+    def transform_frames_device(self, ptr, frame_stride, nframes, w, h, to_cs, sc):
+        self._chk(self.L.lumahip_transform_color_space_device(self.h, ptr, frame_stride, nframes, w, h,
+                                                              int(bool(to_cs)), sc))
+
+    def synth_frames_device(self, ptr, frame_stride, nframes, w, h, seed=20250929, first_frame=0):
+        self._chk(self.L.lumahip_synth_frames_device(self.h, ptr, frame_stride, nframes, w, h, seed, first_frame))
+
+    def time_launches(self, direction, iters, rgb_ptr, frame_stride, nframes, w, h, sc, profile, plane_ptrs, strides,
+                      plane_frame_strides) -> float:
+        """average milliseconds per launch, measured with hipEvents on the context's stream"""
+        ms = C.c_float(0)
+        self._chk(self.L.lumahip_time_launches(self.h, direction, iters, rgb_ptr, frame_stride, nframes, w, h, sc,
+                                               profile, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                               _arr3(C.c_size_t, plane_frame_strides), C.byref(ms)))
+        return float(ms.value)
+
+    # ---- raw device memory (hosts without torch)
+    def malloc(self, nbytes) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.lumahip_malloc(self.h, C.byref(p), nbytes))
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self.L.lumahip_free(self.h, ptr))
+
+    def h2d(self, dst_ptr, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.lumahip_memcpy_h2d(self.h, dst_ptr, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, src_ptr):
+        assert arr.flags.c_contiguous
+        self._chk(self.L.lumahip_memcpy_d2h(self.h, arr.ctypes.data, src_ptr, arr.nbytes))

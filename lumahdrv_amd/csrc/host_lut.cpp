@@ -1,0 +1,98 @@
+// host_lut.cpp -- host-side construction of the transfer-function table, i.e. the part of
+// LumaQuantizer::setQuantizer that stays on the CPU (src/luma_quantizer.cpp:114-169,172-212): at most
+// 65536 libm calls once per stream.  It calls the host libm's powf / log10f exactly as the reference does,
+// so the table is bit-identical to what the reference would write into MKV attachment 434 on this host.
+// PSI / JND-HDR-VDP tables are data (captured by tools/capture_ptf_tables.py) loaded from
+// lumahdrv_amd/data/ptf_<name>_<bits>.f32.
+#include <dlfcn.h>
+#include <math.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lumahip.h"
+
+namespace {
+
+// LumaQuantizer::transformPQ, decode branch (src/luma_quantizer.cpp:496-500); constants are double
+// literals narrowed to float, as in the reference
+float pq_decode_host(float L, float val)
+{
+    const float m = 78.8438, n = 0.1593, c1 = 0.8359, c2 = 18.8516, c3 = 18.6875;
+    float Vp = powf(val, 1.0f / m);
+    return L * powf(std::max(0.0f, (Vp - c1)) / (c2 - c3 * Vp), 1.0f / n);
+}
+
+// LumaQuantizer::transformLog, decode branch (src/luma_quantizer.cpp:509)
+float log_decode_host(float Lmax, float Lmin, float val)
+{
+    return powf(10.0f, val * (log10f(Lmax) - log10f(Lmin)) + log10f(Lmin));
+}
+
+std::string data_dir()
+{
+    if (const char *e = getenv("LUMAHIP_DATA_DIR"))
+        return e;
+    Dl_info info;
+    if (dladdr((const void *)&lumahip_build_lut, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;  // .../lumahdrv_amd/lib/liblumahip.so
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) {
+            p = p.substr(0, s);
+            s = p.rfind('/');
+            if (s != std::string::npos)
+                return p.substr(0, s) + "/data";
+        }
+    }
+    return "lumahdrv_amd/data";
+}
+
+}  // namespace
+
+extern "C" int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, float *out, size_t n)
+{
+    if (!out || bitdepth < 1 || bitdepth > 16 || n != ((size_t)1 << bitdepth))
+        return LUMAHIP_ERR_ARG;
+    const unsigned maxVal = (unsigned)((int)powf(2.0f, (float)bitdepth) - 1);
+    switch (ptf) {
+    case LUMAHIP_PTF_PQ:
+        for (size_t i = 0; i <= maxVal; i++)
+            out[i] = pq_decode_host(maxLum, (float)i / maxVal);
+        return LUMAHIP_OK;
+    case LUMAHIP_PTF_LOG:
+        for (size_t i = 0; i <= maxVal; i++)
+            out[i] = log_decode_host(maxLum, minLum, (float)i / maxVal);
+        return LUMAHIP_OK;
+    case LUMAHIP_PTF_LINEAR:
+        for (size_t i = 0; i <= maxVal; i++)
+            out[i] = maxLum * ((float)i / maxVal);
+        return LUMAHIP_OK;
+    case LUMAHIP_PTF_JND_HDRVDP:
+    case LUMAHIP_PTF_PSI:
+    default: {
+        // the reference selects the 10- or 11-bit table for those depths and the 12-bit table for every
+        // other depth, then copies maxVal+1 entries (src/luma_quantizer.cpp:128-169) -- reading past the
+        // table when bitdepth > 12; that case is rejected here.
+        const unsigned tb = (bitdepth == 10 || bitdepth == 11) ? bitdepth : 12;
+        if (n > ((size_t)1 << tb))
+            return LUMAHIP_ERR_UNSUPPORTED;
+        const char *nm = (ptf == LUMAHIP_PTF_JND_HDRVDP) ? "jnd_hdrvdp" : "psi";
+        char path[1024];
+        snprintf(path, sizeof path, "%s/ptf_%s_%u.f32", data_dir().c_str(), nm, tb);
+        FILE *f = fopen(path, "rb");
+        if (!f)
+            return LUMAHIP_ERR_STATE;
+        std::vector<float> t((size_t)1 << tb);
+        const size_t got = fread(t.data(), sizeof(float), t.size(), f);
+        fclose(f);
+        if (got != t.size())
+            return LUMAHIP_ERR_STATE;
+        memcpy(out, t.data(), n * sizeof(float));
+        return LUMAHIP_OK;
+    }
+    }
+}

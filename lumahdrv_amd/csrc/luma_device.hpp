@@ -1,0 +1,333 @@
+// luma_device.hpp -- per-pixel device arithmetic of the Luma HDRv quantize / dequantize path (gfx950).
+//
+// Bit-exactness rules (DESIGN.md "float semantics"):
+//   * compiled with -ffp-contract=off: every + - * / below is one correctly-rounded fp32 operation,
+//     evaluated in the reference's association order; fmaf() appears only inside the division helpers,
+//     where it is part of a correctly-rounded divide, never as a contraction of reference arithmetic;
+//   * std::min / std::max semantics (libstdc++: min(a,b) = (b<a)?b:a, max(a,b) = (a<b)?b:a) are spelled
+//     out as compare + select: v_min_f32 / v_max_f32 / v_med3_f32 treat NaN differently and the
+//     reference's NaN results (e.g. rgb(NaN,1,1) -> Y=2047,U=255,V=255) are part of parity;
+//   * NaN sign / payload never reaches an output: x86 produces 0xFFC00000 where gfx950 produces
+//     0x7FC00000, so every consumer of a possibly-NaN value decides by ordered compares only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pow_glibc.hpp"
+
+namespace lh {
+
+enum : int { CS_LUV = 0, CS_RGB = 1, CS_YCBCR = 2, CS_XYZ = 3 };
+
+#define LH_DEV static __device__ __forceinline__
+#define LH_DEVS __device__ __forceinline__  // explicit specialisations take no storage class
+
+LH_DEV float std_min(float a, float b) { return (b < a) ? b : a; }
+LH_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
+
+// std::max(std::min(v, 1e8f), 1e-4f): src/luma_quantizer.cpp:285-287,305-307,412-414
+LH_DEV float clamp_xyz(float v) { return std_max(std_min(v, 100000000.0f), 0.0001f); }
+
+// ---------------------------------------------------------------------------------------------------
+// Division.
+//
+// div_ieee(a,b): plain fp32 '/', which hipcc expands to the IEEE-correct v_div_scale / v_rcp /
+// v_fma x5 / v_div_fmas / v_div_fixup sequence (12 VALU ops).
+//
+// div_nr(a,b): the same Newton-Raphson core WITHOUT v_div_scale / v_div_fixup.  For operands whose
+// magnitudes are far from the fp32 exponent limits (no operand or quotient denormal, exponent
+// difference < 96, denominator exponent < 253) v_div_scale returns its input unchanged, v_div_fmas is a
+// plain fma and v_div_fixup passes the quotient through, so the result is bit-identical to div_ieee --
+// and NaN in gives NaN out either way.  Each call site states the operand range that licenses it.
+// rcp_nr(b) exposes the refined reciprocal so that two quotients over one denominator share it.
+// ---------------------------------------------------------------------------------------------------
+LH_DEV float div_ieee(float a, float b) { return a / b; }
+
+#ifdef LH_NO_FAST_DIV  // A/B switch: every division through the compiler's full IEEE sequence
+LH_DEV float rcp_nr(float b) { return b; }
+LH_DEV float div_nr_r(float a, float b, float) { return a / b; }
+LH_DEV float div_nr(float a, float b) { return a / b; }
+#else
+
+LH_DEV float rcp_nr(float b)
+{
+    float r0 = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+
+LH_DEV float div_nr_r(float a, float b, float r1)
+{
+    float q0 = a * r1;
+    float e0 = __builtin_fmaf(-b, q0, a);
+    float q1 = __builtin_fmaf(e0, r1, q0);
+    float e1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e1, r1, q1);
+}
+
+LH_DEV float div_nr(float a, float b) { return div_nr_r(a, b, rcp_nr(b)); }
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Colour transforms, one pixel.  in: r,g,b (already multiplied by nothing); out: the three channel
+// values the reference stores back into the frame.
+// ---------------------------------------------------------------------------------------------------
+
+struct XformConst {
+    float sc;               // preScaling
+    float Lmax;             // PQ peak for the YCbCr path
+    const PowfTables *pw;   // powf tables (LDS copy), YCbCr only
+};
+
+// LumaQuantizer::transformPQ, src/luma_quantizer.cpp:485-501.  The constants are double literals
+// narrowed to `const float` in the reference; 1.0f/m and 1.0f/n are single fp32 divisions.
+LH_DEV float pq_encode(float val, const XformConst &k)
+{
+    const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
+    const float Lp = powf_glibc(div_ieee(val, k.Lmax), n, *k.pw);
+    return powf_glibc(div_ieee(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw);
+}
+
+LH_DEV float pq_decode(float val, const XformConst &k)
+{
+    const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
+    const float Vp = powf_glibc(val, 1.0f / m, *k.pw);
+    return k.Lmax * powf_glibc(div_ieee(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw);
+}
+
+template <int CS>
+LH_DEV void xform_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2);
+
+// RGB -> XYZ: src/luma_quantizer.cpp:273-290 (matrix include/luma/luma_quantizer.h:79-82)
+LH_DEV void rgb_to_xyz(float R, float G, float B, float &X, float &Y, float &Z)
+{
+    X = clamp_xyz((0.412424f * R + 0.357579f * G) + 0.180464f * B);
+    Y = clamp_xyz((0.212656f * R + 0.715158f * G) + 0.072186f * B);
+    Z = clamp_xyz((0.019332f * R + 0.119193f * G) + 0.950444f * B);
+}
+
+template <>
+LH_DEVS void xform_fwd<CS_XYZ>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
+{
+    rgb_to_xyz(r * k.sc, g * k.sc, b * k.sc, c0, c1, c2);
+}
+
+// RGB -> Lu'v': src/luma_quantizer.cpp:291-316
+template <>
+LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
+{
+    float X, Y, Z;
+    rgb_to_xyz(r * k.sc, g * k.sc, b * k.sc, X, Y, Z);
+    const float sum = (X + Y) + Z;
+    // X,Y,Z in [1e-4,1e8] (or NaN) after the clamp, sum in [3e-4,3e8]: div_nr is exact here
+    const float rs = rcp_nr(sum);
+    const float x = div_nr_r(X, sum, rs);
+    const float y = div_nr_r(Y, sum, rs);
+    // x,y in (0,1], x+y<=1+ulp: den = 3 - 2x + 12y in [1,15]; numerators in [1e-12,9]
+    const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
+    const float rd = rcp_nr(den);
+    c0 = Y;
+    c1 = div_ieee(div_nr_r(4.0f * x, den, rd) * 410.f, 255.0f);
+    c2 = div_ieee(div_nr_r(9.0f * y, den, rd) * 410.f, 255.0f);
+}
+
+template <>
+LH_DEVS void xform_fwd<CS_RGB>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
+{
+    // src/luma_quantizer.cpp:355-367
+    c0 = r * k.sc;
+    c1 = g * k.sc;
+    c2 = b * k.sc;
+}
+
+// RGB -> Y'CbCr (BT.2020, PQ): src/luma_quantizer.cpp:317-354
+template <>
+LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
+{
+    const float R = pq_encode(std_max(r * k.sc, 1e-10f), k);
+    const float G = pq_encode(std_max(g * k.sc, 1e-10f), k);
+    const float B = pq_encode(std_max(b * k.sc, 1e-10f), k);
+    const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
+    c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
+    c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
+    c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
+}
+
+template <int CS>
+LH_DEV void xform_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b);
+
+// Y'CbCr -> RGB: src/luma_quantizer.cpp:436-473
+template <>
+LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+{
+    float y = pq_encode(c0, k);
+    y = div_ieee(255.0f * y - 16.0f, 219.0f);
+    float blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
+    float red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
+    float green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
+    red = std_max(0.0f, std_min(1.0f, red));
+    green = std_max(0.0f, std_min(1.0f, green));
+    blue = std_max(0.0f, std_min(1.0f, blue));
+    r = div_ieee(pq_decode(red, k), k.sc);
+    g = div_ieee(pq_decode(green, k), k.sc);
+    b = div_ieee(pq_decode(blue, k), k.sc);
+}
+
+// XYZ -> RGB / sc: src/luma_quantizer.cpp:378-395 (matrix include/luma/luma_quantizer.h:84-87)
+LH_DEV void xyz_to_rgb_sc(float X, float Y, float Z, float sc, float &r, float &g, float &b)
+{
+    r = div_ieee((3.240708f * X + -1.537259f * Y) + -0.498570f * Z, sc);
+    g = div_ieee((-0.969257f * X + 1.875995f * Y) + 0.041555f * Z, sc);
+    b = div_ieee((0.055636f * X + -0.203996f * Y) + 1.057069f * Z, sc);
+}
+
+template <>
+LH_DEVS void xform_inv<CS_XYZ>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+{
+    xyz_to_rgb_sc(c0, c1, c2, k.sc, r, g, b);
+}
+
+// Lu'v' -> RGB: src/luma_quantizer.cpp:396-421
+template <>
+LH_DEVS void xform_inv<CS_LUV>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+{
+    const float L = c0;
+    const float u = div_ieee(c1 * 255.0f, 410.0f);
+    const float v = div_ieee(c2 * 255.0f, 410.0f);
+    const float d = ((6.0f * u) - 16.0f * v) + 12.0f;
+    const float x = div_ieee(9.0f * u, d);
+    const float y = div_ieee(4.0f * v, d);
+    const float Y = clamp_xyz(L);
+    const float X = clamp_xyz(div_ieee(x, y) * L);
+    const float Z = clamp_xyz(div_ieee((1.0f - x) - y, y) * L);
+    xyz_to_rgb_sc(X, Y, Z, k.sc, r, g, b);
+}
+
+template <>
+LH_DEVS void xform_inv<CS_RGB>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+{
+    // src/luma_quantizer.cpp:422-435
+    r = div_ieee(c0, k.sc);
+    g = div_ieee(c1, k.sc);
+    b = div_ieee(c2, k.sc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Quantizer description handed to every kernel by value.
+// ---------------------------------------------------------------------------------------------------
+struct QuantDev {
+    const float *lut;        // global: maxVal+1 floats followed by `pad` NaNs
+    const uint16_t *bucket;  // global: nbuckets bucket starts (mode 1)
+    int lut_len;             // maxVal + 1
+    int pad;
+    int maxVal;
+    int mode;                // lh::LutMode
+    int shift, kmin, nbuckets, steps;
+    float maxC;              // (float)m_maxValColor
+    int cs;
+    float Lmax;
+};
+
+// colour-channel quantizer: floor(maxC*val + 0.5f) clamped with std::min / std::max,
+// src/luma_quantizer.cpp:238-241
+LH_DEV int quantize_color(float val, float maxC)
+{
+    float res = floorf(maxC * val + 0.5f);
+    res = std_min(maxC, res);  // (res < maxC) ? res : maxC   -> NaN becomes maxC
+    res = std_max(0.0f, res);
+    return (int)res;
+}
+
+// colour-channel dequantizer: std::max(val/maxC, 1e-10f), src/luma_quantizer.cpp:261
+LH_DEV float dequantize_color(int code, float maxC) { return std_max(div_ieee((float)code, maxC), 1e-10f); }
+
+// LUT-channel dequantizer, src/luma_quantizer.cpp:253-258 (code is an unsigned sample, so val<0 never holds)
+template <typename LutPtr>
+LH_DEV float dequantize_lut(int code, LutPtr lut, int maxVal)
+{
+    return lut[code < maxVal ? code : maxVal];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LUT-channel quantizer for N values at once (interleaved so the LDS probes of the N searches overlap).
+// ---------------------------------------------------------------------------------------------------
+
+// the reference's loop, literally: src/luma_quantizer.cpp:222-235
+template <typename LutPtr>
+LH_DEV int quantize_lut_literal(float v, LutPtr lut, int maxVal)
+{
+    int l = 0, r = maxVal;
+    while (l + 1 < r) {
+        const int m = (l + r) >> 1;
+        if (v < lut[m])
+            r = m;
+        else
+            l = m;
+    }
+    return ((v - lut[l]) < (lut[r] - v)) ? l : r;
+}
+
+template <int N, typename LutPtr, typename BucketPtr>
+LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
+{
+    int l[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        int k = (__float_as_int(v[i]) >> q.shift) - q.kmin;
+        k = min(max(k, 0), q.nbuckets - 1);
+        l[i] = bucket[k];
+    }
+    for (int s = q.steps - 1; s >= 0; --s) {
+        const int step = 1 << s;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int c = l[i] + step;
+            l[i] = (lut[c] <= v[i]) ? c : l[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int ll = min(l[i], q.maxVal - 1);
+        const float ml = lut[ll], mr = lut[ll + 1];
+        int c = ((v[i] - ml) < (mr - v[i])) ? ll : ll + 1;
+        code[i] = (v[i] != v[i]) ? q.maxVal : c;  // bisection with NaN: every `v < map[m]` is false
+    }
+}
+
+template <int MODE, int N, typename LutPtr, typename BucketPtr>
+LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
+{
+    if constexpr (MODE == 1) {
+        quantize_lut_bucket<N>(v, code, lut, bucket, q);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            code[i] = quantize_lut_literal(v[i], lut, q.maxVal);
+    }
+}
+
+// wave64 reductions (stats)
+LH_DEV float wave_sum(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        x += __shfl_xor(x, o, 64);
+    return x;
+}
+LH_DEV float wave_min(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        x = fminf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+LH_DEV float wave_max(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+}  // namespace lh

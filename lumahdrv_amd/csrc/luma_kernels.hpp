@@ -1,0 +1,580 @@
+// luma_kernels.hpp -- fused encode / decode kernels of the Luma HDRv quantize / dequantize path, gfx950.
+//
+// ENC = LumaQuantizer::transformColorSpace(frame,true,sc) (src/luma_quantizer.cpp:267-373) fused with
+//       LumaEncoder::setChannels / setVpxChannel (src/luma_encoder.cpp:196-201,260-317);
+// DEC = LumaDecoder::getVpxChannels (src/luma_decoder.cpp:205-240) fused with
+//       LumaQuantizer::transformColorSpace(frame,false,sc) (src/luma_quantizer.cpp:374-479).
+//
+// Work decomposition (both directions): a *unit* is VW pixels x 2 rows (VW/2 chroma quads in 4:2:0); a
+// thread owns one unit per tile; a wave owns 64 consecutive units of one row pair (64*VW*4 B = 1 KiB
+// contiguous per load instruction per row and channel); a workgroup of NW waves owns a tile of
+// 64*VW pixels x 2*NW rows; workgroups are persistent and stride over tiles (tile index is
+// wave-uniform, so all index arithmetic on it is scalar).  The transfer-function table and its bucket
+// index are staged once per workgroup in LDS.  No inter-workgroup communication except the optional
+// per-frame statistics (float atomics).
+#pragma once
+
+#include "luma_device.hpp"
+
+namespace lh {
+
+struct FrameGeom {
+    int w, h;            // luma size (even)
+    int unitsX, unitsY;  // w/VW, h/2
+    int tilesX, tilesY;  // ceil(unitsX/64), ceil(unitsY/NW)
+    int tilesPerFrame;
+    int totalTiles;      // tilesPerFrame * nframes
+};
+
+struct EncArgs {
+    QuantDev q;
+    FrameGeom g;
+    const float *src;     // frame f at src + f*frame_stride; channel c at + c*w*h
+    size_t frame_stride;  // floats
+    unsigned char *dst[3];
+    int stride[3];        // bytes
+    size_t dst_frame_stride[3];
+    float sc;
+    int bps;              // bytes per sample: 1 or 2
+    int aligned;          // 1: vector stores allowed
+    float *stats;         // nullable: {sum,min,max} per frame
+};
+
+struct DecArgs {
+    QuantDev q;
+    FrameGeom g;
+    const unsigned char *src[3];
+    int stride[3];
+    size_t src_frame_stride[3];
+    float *dst;
+    size_t frame_stride;
+    float sc;
+    int bps;
+    int aligned;
+};
+
+constexpr int LDS_ALIGN = 16;
+
+// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][bucket: nbuckets u16, rounded to 16 B][powf tables]
+LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
+LH_DEV int lds_bucket_bytes(const QuantDev &q) { return (q.nbuckets * 2 + 15) & ~15; }
+
+template <bool NEED_BUCKET>
+LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, bool lut_in_lds, bool need_pw)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int off = 0;
+    if (lut_in_lds) {
+        // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
+        const int n4 = lds_lut_bytes(q) / 16;
+        const float4 *g = reinterpret_cast<const float4 *>(q.lut);
+        float4 *s = reinterpret_cast<float4 *>(smem);
+        for (int i = tid; i < n4; i += nt)
+            s[i] = g[i];
+        off += lds_lut_bytes(q);
+        if (NEED_BUCKET && q.mode == 1) {
+            const int b4 = lds_bucket_bytes(q) / 16;
+            const uint4 *gb = reinterpret_cast<const uint4 *>(q.bucket);
+            uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
+            for (int i = tid; i < b4; i += nt)
+                sb[i] = gb[i];
+            off += lds_bucket_bytes(q);
+        }
+    }
+    if (need_pw) {
+        PowfTables *t = reinterpret_cast<PowfTables *>(smem + off);
+        const double lt[16][2] = LH_POWF_LOG2_TAB;
+        const uint64_t et[32] = LH_POWF_EXP2_TAB;
+        if (tid < 16) {
+            t->log2_tab[tid][0] = lt[tid][0];
+            t->log2_tab[tid][1] = lt[tid][1];
+        }
+        if (tid < 32)
+            t->exp2_tab[tid] = et[tid];
+    }
+    __syncthreads();
+}
+
+// ---- sample stores / loads ------------------------------------------------------------------------
+
+// N consecutive samples (codes) at p; bps 1 or 2; little-endian 16-bit exactly as
+// src/luma_encoder.cpp:301-307 produces (bl = res/256 at +1, bh = res - bl*256 at +0); the 8-bit path
+// keeps the low byte (the reference's float->unsigned char conversion, quirk 2).
+template <int N>
+LH_DEV void store_samples(unsigned char *p, const int (&c)[N], int bps, int aligned)
+{
+    if (bps == 2) {
+        if (aligned) {
+            if constexpr (N == 4) {
+                uint2 v;
+                v.x = (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16);
+                v.y = (uint32_t)(c[2] & 0xffff) | ((uint32_t)c[3] << 16);
+                *reinterpret_cast<uint2 *>(p) = v;
+            } else if constexpr (N == 2) {
+                *reinterpret_cast<uint32_t *>(p) = (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16);
+            } else {
+                *reinterpret_cast<uint16_t *>(p) = (uint16_t)c[0];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                p[2 * i] = (unsigned char)(c[i] & 0xff);
+                p[2 * i + 1] = (unsigned char)((c[i] >> 8) & 0xff);
+            }
+        }
+    } else {
+        if (aligned) {
+            if constexpr (N == 4) {
+                *reinterpret_cast<uint32_t *>(p) = (uint32_t)(c[0] & 0xff) | ((uint32_t)(c[1] & 0xff) << 8) |
+                                                   ((uint32_t)(c[2] & 0xff) << 16) | ((uint32_t)(c[3] & 0xff) << 24);
+            } else if constexpr (N == 2) {
+                *reinterpret_cast<uint16_t *>(p) = (uint16_t)((c[0] & 0xff) | ((c[1] & 0xff) << 8));
+            } else {
+                p[0] = (unsigned char)(c[0] & 0xff);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                p[i] = (unsigned char)(c[i] & 0xff);
+        }
+    }
+}
+
+// src/luma_decoder.cpp:222-225: buf[2x+1]*256.0f + buf[2x] (exact in fp32) or buf[x]
+template <int N>
+LH_DEV void load_samples(const unsigned char *p, int (&c)[N], int bps, int aligned)
+{
+    if (bps == 2) {
+        if (aligned) {
+            if constexpr (N == 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(p);
+                c[0] = v.x & 0xffff; c[1] = v.x >> 16; c[2] = v.y & 0xffff; c[3] = v.y >> 16;
+            } else if constexpr (N == 2) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                c[0] = v & 0xffff; c[1] = v >> 16;
+            } else {
+                c[0] = *reinterpret_cast<const uint16_t *>(p);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                c[i] = (int)p[2 * i] | ((int)p[2 * i + 1] << 8);
+        }
+    } else {
+        if (aligned) {
+            if constexpr (N == 4) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                c[0] = v & 0xff; c[1] = (v >> 8) & 0xff; c[2] = (v >> 16) & 0xff; c[3] = v >> 24;
+            } else if constexpr (N == 2) {
+                const uint32_t v = *reinterpret_cast<const uint16_t *>(p);
+                c[0] = v & 0xff; c[1] = v >> 8;
+            } else {
+                c[0] = p[0];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                c[i] = p[i];
+        }
+    }
+}
+
+template <int VW>
+LH_DEV void load_px(const float *p, float (&v)[VW])
+{
+    if constexpr (VW == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+}
+
+template <int VW>
+LH_DEV void store_px(float *p, const float (&v)[VW])
+{
+    if constexpr (VW == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    }
+}
+
+LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
+{
+    f = t / g.tilesPerFrame;
+    const int r = t - f * g.tilesPerFrame;
+    by = r / g.tilesX;
+    bx = r - by * g.tilesX;
+}
+
+// ---- ENCODE ---------------------------------------------------------------------------------------
+// CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
+// LM: LUT search mode (lh::LutMode).
+template <int CS, bool SUB, int VW, int LM>
+__global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool LUT_LDS = (LM != 2);
+    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
+    stage_tables<true>(smem, a.q, LUT_LDS, CS == CS_YCBCR);
+
+    const float *s_lut = reinterpret_cast<const float *>(smem);
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
+    const float *lut = LUT_LDS ? s_lut : a.q.lut;
+    int pw_off = 0;
+    if (LUT_LDS)
+        pw_off = lds_lut_bytes(a.q) + ((LM == 1) ? lds_bucket_bytes(a.q) : 0);
+    XformConst k;
+    k.sc = a.sc;
+    k.Lmax = a.q.Lmax;
+    k.pw = reinterpret_cast<const PowfTables *>(smem + pw_off);
+
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const size_t cs = (size_t)a.g.w * a.g.h;  // channel stride (floats)
+    const float maxC = a.q.maxC;
+
+    float st_sum = 0.0f, st_min = __builtin_inff(), st_max = -__builtin_inff();
+    int st_frame = -1;
+
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
+        int f, bx, by;
+        tile_coords(t, a.g, f, bx, by);
+        if (a.stats && f != st_frame) {
+            if (st_frame >= 0) {
+                const float s = wave_sum(st_sum), mn = wave_min(st_min), mx = wave_max(st_max);
+                if (tx == 0) {
+                    atomicAdd(&a.stats[3 * st_frame + 0], s);
+                    atomicMin(&a.stats[3 * st_frame + 1], mn);
+                    atomicMax(&a.stats[3 * st_frame + 2], mx);
+                }
+            }
+            st_sum = 0.0f; st_min = __builtin_inff(); st_max = -__builtin_inff();
+            st_frame = f;
+        }
+        const int ux = bx * 64 + tx, uy = by * NW + ty;
+        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
+            continue;
+
+        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * VW;
+        float in[3][2][VW];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            load_px<VW>(p + c * cs, in[c][0]);
+            load_px<VW>(p + c * cs + a.g.w, in[c][1]);
+        }
+        // colour transform (row-major pixel order inside the unit: j = r*VW + i)
+        float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                xform_fwd<CS>(in[0][r][i], in[1][r][i], in[2][r][i], k, c0[r * VW + i], c1[r * VW + i], c2[r * VW + i]);
+
+        if (a.stats) {
+#pragma unroll
+            for (int j = 0; j < 2 * VW; j++) {
+                st_sum += c0[j];
+                st_min = fminf(st_min, c0[j]);
+                st_max = fmaxf(st_max, c0[j]);
+            }
+        }
+
+        // plane 0
+        int code0[2 * VW];
+        quantize_lut<LM, 2 * VW>(c0, code0, lut, s_bucket, a.q);
+        {
+            unsigned char *d = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
+                               (size_t)ux * VW * a.bps;
+            int row[VW];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    row[i] = code0[r * VW + i];
+                store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
+            }
+        }
+
+        // planes 1, 2
+        if constexpr (SUB) {
+            constexpr int NQ = VW / 2;
+            float a1[NQ], a2[NQ];
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++) {
+                // src/luma_encoder.cpp:287-289: 0.25f*(src[i] + src[i+1] + src[i+2w] + src[i+2w+1])
+                a1[qd] = 0.25f * (((c1[2 * qd] + c1[2 * qd + 1]) + c1[VW + 2 * qd]) + c1[VW + 2 * qd + 1]);
+                a2[qd] = 0.25f * (((c2[2 * qd] + c2[2 * qd + 1]) + c2[VW + 2 * qd]) + c2[VW + 2 * qd + 1]);
+            }
+            int k1[NQ], k2[NQ];
+            if constexpr (LUT_ALL) {
+                quantize_lut<LM, NQ>(a1, k1, lut, s_bucket, a.q);
+                quantize_lut<LM, NQ>(a2, k2, lut, s_bucket, a.q);
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < NQ; qd++) {
+                    k1[qd] = quantize_color(a1[qd], maxC);
+                    k2[qd] = quantize_color(a2[qd], maxC);
+                }
+            }
+            store_samples<NQ>(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] +
+                                  (size_t)ux * NQ * a.bps, k1, a.bps, a.aligned);
+            store_samples<NQ>(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] +
+                                  (size_t)ux * NQ * a.bps, k2, a.bps, a.aligned);
+        } else {
+            int k1[2 * VW], k2[2 * VW];
+            if constexpr (LUT_ALL) {
+                quantize_lut<LM, 2 * VW>(c1, k1, lut, s_bucket, a.q);
+                quantize_lut<LM, 2 * VW>(c2, k2, lut, s_bucket, a.q);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2 * VW; j++) {
+                    k1[j] = quantize_color(c1[j], maxC);
+                    k2[j] = quantize_color(c2[j], maxC);
+                }
+            }
+#pragma unroll
+            for (int pl = 1; pl < 3; pl++) {
+                unsigned char *d = a.dst[pl] + (size_t)f * a.dst_frame_stride[pl] + (size_t)(2 * uy) * a.stride[pl] +
+                                   (size_t)ux * VW * a.bps;
+                int row[VW];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+#pragma unroll
+                    for (int i = 0; i < VW; i++)
+                        row[i] = (pl == 1) ? k1[r * VW + i] : k2[r * VW + i];
+                    store_samples<VW>(d + (size_t)r * a.stride[pl], row, a.bps, a.aligned);
+                }
+            }
+        }
+    }
+    if (a.stats && st_frame >= 0) {
+        const float s = wave_sum(st_sum), mn = wave_min(st_min), mx = wave_max(st_max);
+        if (tx == 0) {
+            atomicAdd(&a.stats[3 * st_frame + 0], s);
+            atomicMin(&a.stats[3 * st_frame + 1], mn);
+            atomicMax(&a.stats[3 * st_frame + 2], mx);
+        }
+    }
+}
+
+// ---- DECODE ---------------------------------------------------------------------------------------
+// GL: LUT read from global memory (bitdepth > 12) instead of LDS
+template <int CS, bool SUB, int VW, bool GL>
+__global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
+    stage_tables<false>(smem, a.q, !GL, CS == CS_YCBCR);
+    const float *s_lut = reinterpret_cast<const float *>(smem);
+    const float *lut = GL ? a.q.lut : s_lut;
+    XformConst k;
+    k.sc = a.sc;
+    k.Lmax = a.q.Lmax;
+    k.pw = reinterpret_cast<const PowfTables *>(smem + (GL ? 0 : lds_lut_bytes(a.q)));
+
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const size_t cs = (size_t)a.g.w * a.g.h;
+    const float maxC = a.q.maxC;
+    const int maxVal = a.q.maxVal;
+
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
+        int f, bx, by;
+        tile_coords(t, a.g, f, bx, by);
+        const int ux = bx * 64 + tx, uy = by * NW + ty;
+        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
+            continue;
+
+        float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+        {
+            const unsigned char *s = a.src[0] + (size_t)f * a.src_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
+                                     (size_t)ux * VW * a.bps;
+            int row[VW];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                load_samples<VW>(s + (size_t)r * a.stride[0], row, a.bps, a.aligned);
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    c0[r * VW + i] = dequantize_lut(row[i], lut, maxVal);
+            }
+        }
+        if constexpr (SUB) {
+            constexpr int NQ = VW / 2;
+            int k1[NQ], k2[NQ];
+            load_samples<NQ>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)uy * a.stride[1] +
+                                 (size_t)ux * NQ * a.bps, k1, a.bps, a.aligned);
+            load_samples<NQ>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)uy * a.stride[2] +
+                                 (size_t)ux * NQ * a.bps, k2, a.bps, a.aligned);
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++) {
+                const float v1 = LUT_ALL ? dequantize_lut(k1[qd], lut, maxVal) : dequantize_color(k1[qd], maxC);
+                const float v2 = LUT_ALL ? dequantize_lut(k2[qd], lut, maxVal) : dequantize_color(k2[qd], maxC);
+                // src/luma_decoder.cpp:229-234: the sample is replicated to its 2x2 block
+                c1[2 * qd] = c1[2 * qd + 1] = c1[VW + 2 * qd] = c1[VW + 2 * qd + 1] = v1;
+                c2[2 * qd] = c2[2 * qd + 1] = c2[VW + 2 * qd] = c2[VW + 2 * qd + 1] = v2;
+            }
+        } else {
+#pragma unroll
+            for (int pl = 1; pl < 3; pl++) {
+                const unsigned char *s = a.src[pl] + (size_t)f * a.src_frame_stride[pl] +
+                                         (size_t)(2 * uy) * a.stride[pl] + (size_t)ux * VW * a.bps;
+                int row[VW];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    load_samples<VW>(s + (size_t)r * a.stride[pl], row, a.bps, a.aligned);
+#pragma unroll
+                    for (int i = 0; i < VW; i++) {
+                        const float v = LUT_ALL ? dequantize_lut(row[i], lut, maxVal) : dequantize_color(row[i], maxC);
+                        if (pl == 1)
+                            c1[r * VW + i] = v;
+                        else
+                            c2[r * VW + i] = v;
+                    }
+                }
+            }
+        }
+
+        float out[3][2][VW];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
+
+        float *p = a.dst + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * VW;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            store_px<VW>(p + c * cs, out[c][0]);
+            store_px<VW>(p + c * cs + a.g.w, out[c][1]);
+        }
+    }
+}
+
+// ---- stand-alone colour transform (LumaQuantizer::transformColorSpace as public API) ---------------
+struct XfArgs {
+    float *buf;
+    size_t frame_stride;
+    size_t chan_stride;  // w*h
+    size_t n2;           // pixel pairs per frame
+    int nframes;
+    float sc;
+    float Lmax;
+};
+
+template <int CS, bool FWD>
+__global__ __launch_bounds__(256) void k_transform(const XfArgs a)
+{
+    __shared__ PowfTables s_pw;
+    if constexpr (CS == CS_YCBCR) {
+        const double lt[16][2] = LH_POWF_LOG2_TAB;
+        const uint64_t et[32] = LH_POWF_EXP2_TAB;
+        if (threadIdx.x < 16) {
+            s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
+            s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
+        }
+        if (threadIdx.x < 32)
+            s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+        __syncthreads();
+    }
+    XformConst k;
+    k.sc = a.sc;
+    k.Lmax = a.Lmax;
+    k.pw = &s_pw;
+    const size_t total = a.n2 * a.nframes;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / a.n2, j = i - f * a.n2;
+        float *p = a.buf + f * a.frame_stride + 2 * j;
+        float v0[2], v1[2], v2[2], o0[2], o1[2], o2[2];
+        load_px<2>(p, v0);
+        load_px<2>(p + a.chan_stride, v1);
+        load_px<2>(p + 2 * a.chan_stride, v2);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if constexpr (FWD)
+                xform_fwd<CS>(v0[e], v1[e], v2[e], k, o0[e], o1[e], o2[e]);
+            else
+                xform_inv<CS>(v0[e], v1[e], v2[e], k, o0[e], o1[e], o2[e]);
+        }
+        store_px<2>(p, o0);
+        store_px<2>(p + a.chan_stride, o1);
+        store_px<2>(p + 2 * a.chan_stride, o2);
+    }
+}
+
+// ---- array quantize / dequantize (LumaQuantizer::quantize / dequantize over arrays) ----------------
+struct QArrArgs {
+    QuantDev q;
+    const float *in;
+    float *out;
+    size_t n;
+    int lut_channel;  // 1: LUT path, 0: colour path
+};
+
+__global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool lds = a.q.mode != 2;
+    stage_tables<true>(smem, a.q, lds, false);
+    const float *s_lut = reinterpret_cast<const float *>(smem);
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v[1] = {a.in[i]};
+        int c[1];
+        if (!a.lut_channel)
+            c[0] = quantize_color(v[0], a.q.maxC);
+        else if (a.q.mode == 1)
+            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);
+        else if (a.q.mode == 0)
+            quantize_lut<0, 1>(v, c, s_lut, s_bucket, a.q);
+        else
+            quantize_lut<2, 1>(v, c, a.q.lut, s_bucket, a.q);
+        a.out[i] = (float)c[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
+{
+    // src/luma_quantizer.cpp:247-264 with a float argument (may be negative, fractional or NaN)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float val = a.in[i];
+        float res;
+        if (a.lut_channel) {
+            if (val < 0)
+                res = a.q.lut[0];
+            else if (val >= (float)a.q.maxVal)
+                res = a.q.lut[a.q.maxVal];
+            else
+                res = a.q.lut[(val != val) ? a.q.maxVal : (int)val];
+        } else {
+            res = std_max(div_ieee(val, a.q.maxC), 1e-10f);
+        }
+        a.out[i] = res;
+    }
+}
+
+// ---- synthetic frames --------------------------------------------------------------
+LH_DEV uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_synth(float *dst, size_t frame_stride, int nframes, size_t n3, uint64_t seed,
+                                                uint64_t first_frame)
+{
+    const size_t total = n3 * nframes;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n3, j = i - f * n3;  // j = ch*h*w + idx
+        const uint64_t h64 = splitmix64(seed ^ ((first_frame + f) * 0x9E3779B97F4A7C15ull) ^ (uint64_t)j);
+        const uint32_t e = 117u + (uint32_t)((h64 >> 40) % 24u);
+        const uint32_t bits = (e << 23) + (uint32_t)(h64 & 0x7FE000u);
+        dst[f * frame_stride + j] = __uint_as_float(bits);
+    }
+}
+
+}  // namespace lh

@@ -1,0 +1,777 @@
+// lumahip_capi.hip -- implementation of include/lumahip.h: context, quantizer upload, kernel dispatch.
+// Host-side only logic here; the arithmetic is in luma_device.hpp / luma_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lumahip.h"
+#include "luma_kernels.hpp"
+#include "lut_index.hpp"
+
+using namespace lh;
+
+struct lumahip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cu = 256;
+
+    bool have_quant = false;
+    int ptf = 0;
+    unsigned bitdepth = 0, bitdepthC = 0;
+    QuantDev q{};
+    LutIndex idx;
+    float *d_lut = nullptr;
+    uint16_t *d_bucket = nullptr;
+    float minLum = 0.0f;
+
+    // staging for the _host entry points
+    float *d_frame = nullptr;
+    size_t d_frame_cap = 0;
+    unsigned char *d_planes = nullptr;
+    size_t d_planes_cap = 0;
+    float *d_stats = nullptr;
+    float *d_arr = nullptr;
+    size_t d_arr_cap = 0;
+
+    int block_threads = 256;
+    int blocks_per_cu = 0;  // 0 = occupancy query
+};
+
+static int fail(lumahip_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail((c), LUMAHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                             \
+    } while (0)
+
+extern "C" int lumahip_abi_version(void) { return LUMAHIP_ABI_VERSION; }
+
+extern "C" int lumahip_device_count(int *count)
+{
+    if (!count)
+        return LUMAHIP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return LUMAHIP_ERR_HIP;
+    }
+    *count = n;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_create(lumahip_ctx **out, int device)
+{
+    if (!out)
+        return LUMAHIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return LUMAHIP_ERR_HIP;  // no CPU fallback: the path needs a HIP device
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess)
+            return LUMAHIP_ERR_HIP;
+    }
+    if (device >= n)
+        return LUMAHIP_ERR_ARG;
+    lumahip_ctx *c = new lumahip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return LUMAHIP_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        c->num_cu = prop.multiProcessorCount;
+    if (const char *e = getenv("LUMAHIP_BLOCK")) {
+        int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024)
+            c->block_threads = v;
+    }
+    if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
+        c->blocks_per_cu = atoi(e);
+    *out = c;
+    return LUMAHIP_OK;
+}
+
+extern "C" void lumahip_destroy(lumahip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_bucket);
+    (void)hipFree(c->d_frame);
+    (void)hipFree(c->d_planes);
+    (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_arr);
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char *lumahip_last_error(const lumahip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int lumahip_set_stream(lumahip_ctx *c, void *s)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_sync(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------- quantizer
+
+extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth, int cs, unsigned bitdepthC,
+                                     float maxLum, float minLum, const float *lut, size_t n)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (bitdepth < 1 || bitdepth > 16 || bitdepthC < 1 || bitdepthC > 16)
+        return fail(c, LUMAHIP_ERR_ARG, "bit depths must be 1..16 (got %u / %u)", bitdepth, bitdepthC);
+    if (!lut || n != ((size_t)1 << bitdepth))
+        return fail(c, LUMAHIP_ERR_ARG, "LUT must hold 2^bitdepth = %zu floats (got %zu)", (size_t)1 << bitdepth, n);
+    if (ptf < 0 || ptf > 4)
+        return fail(c, LUMAHIP_ERR_ARG, "unknown transfer function %d", ptf);
+    // an unknown colour space is accepted here, as in the reference (setQuantizer stores it blindly,
+    // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    c->idx = build_lut_index(lut, (int)n);
+    const LutIndex &ix = c->idx;
+    const size_t lut_floats = ((n + ix.pad) + 3) & ~(size_t)3;
+    std::vector<float> padded(lut_floats, __builtin_nanf(""));
+    memcpy(padded.data(), lut, n * sizeof(float));
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_bucket);
+    c->d_lut = nullptr;
+    c->d_bucket = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
+    const size_t nb = ((size_t)ix.nbuckets + 7) & ~(size_t)7;
+    if (nb) {
+        std::vector<uint16_t> b(nb, 0);
+        memcpy(b.data(), ix.start.data(), ix.nbuckets * sizeof(uint16_t));
+        HIPCHK(c, hipMalloc(&c->d_bucket, nb * sizeof(uint16_t)));
+        HIPCHK(c, hipMemcpy(c->d_bucket, b.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    QuantDev &q = c->q;
+    q.lut = c->d_lut;
+    q.bucket = c->d_bucket;
+    q.lut_len = (int)n;
+    q.pad = (int)(lut_floats - n);
+    q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
+    q.mode = ix.mode;
+    q.shift = ix.shift;
+    q.kmin = ix.kmin;
+    q.nbuckets = ix.nbuckets;
+    q.steps = ix.steps;
+    q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);        // src/luma_quantizer.cpp:183
+    q.cs = cs;
+    q.Lmax = maxLum;
+    c->ptf = ptf;
+    c->bitdepth = bitdepth;
+    c->bitdepthC = bitdepthC;
+    c->minLum = minLum;
+    c->have_quant = true;
+    return LUMAHIP_OK;
+}
+
+static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket, bool force_global = false)
+{
+    const QuantDev &q = c->q;
+    size_t b = 0;
+    if (q.mode != LUT_LITERAL_GLOBAL && !force_global) {
+        b += ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
+        if (need_bucket && q.mode == LUT_BUCKET_LDS)
+            b += ((size_t)q.nbuckets * 2 + 15) & ~(size_t)15;
+    }
+    if (q.cs == CS_YCBCR)
+        b += sizeof(PowfTables);
+    return b;
+}
+
+extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return LUMAHIP_ERR_STATE;
+    info[0] = c->idx.mode;
+    info[1] = c->idx.mant_bits;
+    info[2] = c->idx.nbuckets;
+    info[3] = c->idx.steps;
+    info[4] = (int)lds_bytes(c, true);
+    return LUMAHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------- dispatch
+
+typedef void (*enc_kernel_t)(const EncArgs);
+typedef void (*dec_kernel_t)(const DecArgs);
+
+template <int CS, bool SUB>
+static enc_kernel_t pick_enc2(int vw, int mode)
+{
+    if (mode == LUT_BUCKET_LDS)
+        return vw == 4 ? k_encode<CS, SUB, 4, 1> : k_encode<CS, SUB, 2, 1>;
+    if (mode == LUT_LITERAL_LDS)
+        return k_encode<CS, SUB, 2, 0>;
+    return k_encode<CS, SUB, 2, 2>;
+}
+
+static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
+{
+    switch (cs) {
+    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode) : pick_enc2<CS_LUV, false>(vw, mode);
+    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode) : pick_enc2<CS_RGB, false>(vw, mode);
+    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode) : pick_enc2<CS_YCBCR, false>(vw, mode);
+    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode) : pick_enc2<CS_XYZ, false>(vw, mode);
+    }
+    return nullptr;
+}
+
+template <int CS, bool SUB>
+static dec_kernel_t pick_dec2(int vw, bool gl)
+{
+    if (gl)
+        return k_decode<CS, SUB, 2, true>;
+    return vw == 4 ? k_decode<CS, SUB, 4, false> : k_decode<CS, SUB, 2, false>;
+}
+
+static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl)
+{
+    switch (cs) {
+    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl) : pick_dec2<CS_LUV, false>(vw, gl);
+    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl) : pick_dec2<CS_RGB, false>(vw, gl);
+    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl) : pick_dec2<CS_YCBCR, false>(vw, gl);
+    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl) : pick_dec2<CS_XYZ, false>(vw, gl);
+    }
+    return nullptr;
+}
+
+static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile)
+{
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set (call lumahip_set_quantizer first)");
+    if (w == 0 || h == 0 || (w & 1) || (h & 1))
+        return fail(c, LUMAHIP_ERR_ARG, "Invalid frame size %ux%u (must be even, non-zero)", w, h);
+    if (profile < 0 || profile > 3)
+        return fail(c, LUMAHIP_ERR_ARG, "profile must be 0..3 (got %d)", profile);
+    if (c->q.cs < 0 || c->q.cs > 3)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", c->q.cs);
+    return LUMAHIP_OK;
+}
+
+static void make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes)
+{
+    g.w = (int)w;
+    g.h = (int)h;
+    g.unitsX = (int)w / vw;
+    g.unitsY = (int)h / 2;
+    g.tilesX = (g.unitsX + 63) / 64;
+    g.tilesY = (g.unitsY + nw - 1) / nw;
+    g.tilesPerFrame = g.tilesX * g.tilesY;
+    g.totalTiles = g.tilesPerFrame * (int)nframes;
+}
+
+template <typename K>
+static int grid_for(lumahip_ctx *c, K kern, int threads, size_t lds, int total_tiles)
+{
+    int per_cu = c->blocks_per_cu;
+    if (per_cu <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds) != hipSuccess || occ <= 0)
+            occ = 2;
+        per_cu = occ;
+        const int cap = 2048 / threads;  // 32 waves per CU
+        if (per_cu > cap)
+            per_cu = cap;
+    }
+    long g = (long)c->num_cu * per_cu;
+    if (g > total_tiles)
+        g = total_tiles;
+    if (g < 1)
+        g = 1;
+    return (int)g;
+}
+
+static bool is_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+__global__ void k_init_stats(float *s, int nframes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nframes) {
+        s[3 * i + 0] = 0.0f;
+        s[3 * i + 1] = __builtin_inff();
+        s[3 * i + 2] = -__builtin_inff();
+    }
+}
+
+extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
+                                            unsigned w, unsigned h, float sc, int profile,
+                                            unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], float *stats)
+{
+    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    const int mode = c->q.mode;
+    int vw = (mode == LUT_BUCKET_LDS && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    EncArgs a{};
+    a.q = c->q;
+    const int threads = c->block_threads;
+    make_geom(a.g, w, h, vw, threads / 64, nframes);
+    a.src = rgb;
+    a.frame_stride = frame_stride;
+    a.sc = sc;
+    a.bps = bps;
+    a.stats = stats;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        if (!planes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "null plane %d", p);
+        a.dst[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.dst_frame_stride[p] = pfs[p];
+        const size_t ub = (size_t)((p && sub) ? vw / 2 : vw) * bps;
+        if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
+            a.aligned = 0;
+    }
+    enc_kernel_t kern = pick_enc(c->q.cs, sub, vw, mode);
+    const size_t lds = lds_bytes(c, true);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = grid_for(c, kern, threads, lds, a.g.totalTiles);
+    if (stats)
+        hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                            float sc, float *rgb, size_t frame_stride)
+{
+    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    const bool gl = (c->q.mode == LUT_LITERAL_GLOBAL);
+    int vw = (!gl && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    DecArgs a{};
+    a.q = c->q;
+    const int threads = c->block_threads;
+    make_geom(a.g, w, h, vw, threads / 64, nframes);
+    a.dst = rgb;
+    a.frame_stride = frame_stride;
+    a.sc = sc;
+    a.bps = bps;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        if (!planes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "null plane %d", p);
+        a.src[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.src_frame_stride[p] = pfs[p];
+        const size_t ub = (size_t)((p && sub) ? vw / 2 : vw) * bps;
+        if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
+            a.aligned = 0;
+    }
+    dec_kernel_t kern = pick_dec(c->q.cs, sub, vw, gl);
+    const size_t lds = lds_bytes(c, false);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = grid_for(c, kern, threads, lds, a.g.totalTiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+typedef void (*xf_kernel_t)(const XfArgs);
+static xf_kernel_t pick_xf(int cs, bool fwd)
+{
+    switch (cs) {
+    case CS_LUV: return fwd ? k_transform<CS_LUV, true> : k_transform<CS_LUV, false>;
+    case CS_RGB: return fwd ? k_transform<CS_RGB, true> : k_transform<CS_RGB, false>;
+    case CS_YCBCR: return fwd ? k_transform<CS_YCBCR, true> : k_transform<CS_YCBCR, false>;
+    case CS_XYZ: return fwd ? k_transform<CS_XYZ, true> : k_transform<CS_XYZ, false>;
+    }
+    return nullptr;
+}
+
+extern "C" int lumahip_transform_color_space_device(lumahip_ctx *c, float *frames, size_t frame_stride, unsigned nframes,
+                                                    unsigned w, unsigned h, int toCs, float sc)
+{
+    if (!c || !frames || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "empty frame");
+    if (c->q.cs < 0 || c->q.cs > 3)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Error! Unrecognized color transformation");
+    const size_t n = (size_t)w * h;
+    if ((n & 1) || !is_aligned(frames, 8) || (frame_stride & 1))
+        return fail(c, LUMAHIP_ERR_ARG, "transform needs an even pixel count and 8-byte aligned frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    XfArgs a{};
+    a.buf = frames;
+    a.frame_stride = frame_stride;
+    a.chan_stride = n;
+    a.n2 = n / 2;
+    a.nframes = (int)nframes;
+    a.sc = sc;
+    a.Lmax = c->q.Lmax;
+    xf_kernel_t kern = pick_xf(c->q.cs, toCs != 0);
+    size_t total = a.n2 * nframes;
+    long grid = (long)((total + 255) / 256);
+    const long cap = (long)c->num_cu * 8;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_synth_frames_device(lumahip_ctx *c, float *dst, size_t frame_stride, unsigned nframes, unsigned w,
+                                           unsigned h, uint64_t seed, uint64_t first_frame)
+{
+    if (!c || !dst || nframes == 0 || w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n3 = (size_t)3 * w * h;
+    size_t total = n3 * nframes;
+    long grid = (long)((total + 255) / 256);
+    const long cap = (long)c->num_cu * 16;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)grid), dim3(256), 0, c->stream, dst, frame_stride, (int)nframes, n3, seed,
+                       first_frame);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const float *rgb, size_t frame_stride,
+                                     unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                                     unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                                     float *avg_ms)
+{
+    if (!c || iters <= 0 || !avg_ms)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    int rc = LUMAHIP_OK;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters && rc == LUMAHIP_OK; i++) {
+        if (dir == 0)
+            rc = lumahip_encode_frames_device(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, nullptr);
+        else
+            rc = lumahip_decode_frames_device(c, (const unsigned char *const *)planes, stride, pfs, nframes, w, h, profile,
+                                              sc, const_cast<float *>(rgb), frame_stride);
+    }
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / iters;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------- host entry points
+
+static int ensure(lumahip_ctx *c, void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need)
+        return LUMAHIP_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc(p, need));
+    *cap = need;
+    return LUMAHIP_OK;
+}
+
+struct PlaneLayout {
+    int rows[3];
+    int row_bytes[3];
+    size_t off[3];
+    size_t total;
+};
+
+static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, const int stride[3])
+{
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    size_t off = 0;
+    for (int p = 0; p < 3; p++) {
+        const int pw = (p && sub) ? (int)(w + 1) / 2 : (int)w;
+        const int ph = (p && sub) ? (int)(h + 1) / 2 : (int)h;
+        L.rows[p] = ph;
+        L.row_bytes[p] = pw * bps;
+        L.off[p] = off;
+        off += ((size_t)ph * stride[p] + 255) & ~(size_t)255;
+    }
+    L.total = off;
+}
+
+extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                         unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                                         float *transformed_out)
+{
+    if (!c || !rgb || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int bps = profile > 1 ? 2 : 1;
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride %d < row bytes %d", p, stride[p], L.row_bytes[p]);
+    (void)bps;
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, nfl * sizeof(float))))
+        return rc;
+    if ((rc = ensure(c, (void **)&c->d_planes, &c->d_planes_cap, L.total)))
+        return rc;
+    if (!c->d_stats)
+        HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
+    HIPCHK(c, hipMemcpyAsync(c->d_frame, rgb, nfl * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
+    const size_t pfs[3] = {0, 0, 0};
+    rc = lumahip_encode_frames_device(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats);
+    if (rc)
+        return rc;
+    for (int p = 0; p < 3; p++)
+        HIPCHK(c, hipMemcpy2DAsync(planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p],
+                                   hipMemcpyDeviceToHost, c->stream));
+    float st[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    if (transformed_out) {
+        rc = lumahip_transform_color_space_device(c, c->d_frame, nfl, 1, w, h, 1, sc);
+        if (rc)
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(transformed_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mean_lum)
+        *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                         unsigned w, unsigned h, int profile, float sc, float *rgb_out)
+{
+    if (!c || !rgb_out || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride %d < row bytes %d", p, stride[p], L.row_bytes[p]);
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, nfl * sizeof(float))))
+        return rc;
+    if ((rc = ensure(c, (void **)&c->d_planes, &c->d_planes_cap, L.total)))
+        return rc;
+    unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
+    for (int p = 0; p < 3; p++)
+        HIPCHK(c, hipMemcpy2DAsync(dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p],
+                                   hipMemcpyHostToDevice, c->stream));
+    const size_t pfs[3] = {0, 0, 0};
+    rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(rgb_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_transform_color_space_host(lumahip_ctx *c, float *frame, unsigned w, unsigned h, int toCs, float sc)
+{
+    if (!c || !frame)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (c->q.cs < 0 || c->q.cs > 3)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Error! Unrecognized color transformation");
+    if (w == 0 || h == 0)
+        return LUMAHIP_OK;  // the reference loops zero times and returns true
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h, nfl = 3 * n;
+    // device copy padded to an even pixel count per channel so the pair kernel applies to odd sizes too
+    const size_t npad = (n + 1) & ~(size_t)1;
+    int rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, 3 * npad * sizeof(float));
+    if (rc)
+        return rc;
+    if (npad == n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_frame, frame, nfl * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_frame, 0, 3 * npad * sizeof(float), c->stream));
+        for (int ch = 0; ch < 3; ch++)
+            HIPCHK(c, hipMemcpyAsync(c->d_frame + ch * npad, frame + ch * n, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    // the kernel addresses channels at chan_stride = (w*h); present the padded buffer as a (npad x 1) frame
+    rc = lumahip_transform_color_space_device(c, c->d_frame, 3 * npad, 1, (unsigned)npad, 1, toCs, sc);
+    if (rc)
+        return rc;
+    if (npad == n) {
+        HIPCHK(c, hipMemcpyAsync(frame, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        for (int ch = 0; ch < 3; ch++)
+            HIPCHK(c, hipMemcpyAsync(frame + ch * n, c->d_frame + ch * npad, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch, bool quant)
+{
+    if (!c || !in || !out)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (n == 0)
+        return LUMAHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, 2 * n * sizeof(float));
+    if (rc)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_arr, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    QArrArgs a{};
+    a.q = c->q;
+    a.in = c->d_arr;
+    a.out = c->d_arr + n;
+    a.n = n;
+    // src/luma_quantizer.cpp:219,251: LUT path for ch 0 and for every channel of RGB / XYZ
+    a.lut_channel = (ch == 0 || c->q.cs == CS_RGB || c->q.cs == CS_XYZ) ? 1 : 0;
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    if (quant) {
+        QuantDev saved = a.q;
+        (void)saved;
+        size_t lds = 0;
+        if (c->q.mode != LUT_LITERAL_GLOBAL) {
+            lds = ((size_t)(c->q.lut_len + c->q.pad) * 4 + 15) & ~(size_t)15;
+            if (c->q.mode == LUT_BUCKET_LDS)
+                lds += ((size_t)c->q.nbuckets * 2 + 15) & ~(size_t)15;
+        }
+        hipLaunchKernelGGL(k_quantize_array, dim3((unsigned)grid), dim3(256), lds, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_dequantize_array, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_arr + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantize_array_host(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch)
+{
+    return array_op(c, in, out, n, ch, true);
+}
+
+extern "C" int lumahip_dequantize_array_host(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch)
+{
+    return array_op(c, in, out, n, ch, false);
+}
+
+// ---------------------------------------------------------------------------------------- memory helpers
+
+extern "C" int lumahip_malloc(lumahip_ctx *c, void **p, size_t bytes)
+{
+    if (!c || !p)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(p, bytes));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_free(lumahip_ctx *c, void *p)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(p));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_memcpy_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_memcpy_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}

@@ -1,0 +1,201 @@
+// pow_glibc.hpp -- powf(x, y) with the results of glibc 2.35's libm on x86-64 (FMA ifunc variant),
+// usable on the device (gfx950 fp64 VALU) and on the host.
+//
+// Why: the reference's YCbCr (BT.2020 + PQ) colour transform calls libm powf eight times per pixel
+// (LumaQuantizer::transformPQ, src/luma_quantizer.cpp:485-501, call sites :331-337 and :447-459).  The
+// arithmetic therefore lives in a third-party dependency that is not in the reference tree and that the
+// reference does not pin: glibc libm (this image: 2.35-0ubuntu3.11).  Bit-exact Y/Cb/Cr planes need that
+// function's exact results, not a correctly-rounded powf: glibc's powf differs from the correctly
+// rounded result for ~0.05-0.2 % of arguments.
+//
+// What is restated: glibc's sysdeps/ieee754/flt-32/e_powf.c (Szabolcs Nagy's algorithm, also published
+// in ARM optimized-routines, math/powf.c): x^y = exp2(y * log2(x)) evaluated in binary64 with a 16-entry
+// log2 table + degree-5 polynomial and a 32-entry exp2 table + degree-3 polynomial, no rounding-mode or
+// errno handling (WANT_ROUNDING / errno affect only flags, not values, in round-to-nearest).  x86-64
+// glibc selects __powf_fma at load time on any CPU with FMA+AVX2 (every host this runs on); in that
+// build each `a*b + c` of the source is one fused multiply-add.  The restatement spells those fma()s
+// out explicitly, so it does not depend on compiler contraction, host CPU or GPU.
+//
+// Constants: __powf_log2_data (POWF_LOG2_TABLE_BITS=4, POWF_LOG2_POLY_ORDER=5, POWF_SCALE_BITS=0) and
+// __exp2f_data (EXP2F_TABLE_BITS=5) as published; the 32 exp2 table words equal
+// bits(RN(2^(i/32))) - (i << 47) and were cross-checked against that formula, the log2 table against
+// the bytes of this image's libm.so.6.  tests/test_powf.py compares the restatement with the host
+// libm powf (exhaustively for the four PQ exponents with tools/verify_powf, sampled in the suite).
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LH_HD __host__ __device__ __forceinline__
+#else
+#define LH_HD inline
+#endif
+
+namespace lh {
+
+struct PowfTables {
+    // {invc, logc} x 16, then 32 exp2 table words reinterpreted as double bit patterns
+    double log2_tab[16][2];
+    uint64_t exp2_tab[32];
+};
+
+// clang-format off
+#define LH_POWF_LOG2_TAB { \
+  { 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 }, { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 }, \
+  { 0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2 }, { 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2 }, \
+  { 0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2 }, { 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3 }, \
+  { 0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3 }, { 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4 }, \
+  { 0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5 }, { 0x1p+0, 0x0p+0 }, \
+  { 0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4 },  { 0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3 }, \
+  { 0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3 },  { 0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2 }, \
+  { 0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2 },  { 0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2 } }
+#define LH_POWF_EXP2_TAB { \
+  0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, \
+  0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, \
+  0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, \
+  0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, \
+  0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, \
+  0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, \
+  0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, \
+  0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull }
+// clang-format on
+
+static const PowfTables kPowfTablesHost = {LH_POWF_LOG2_TAB, LH_POWF_EXP2_TAB};
+
+LH_HD uint32_t pw_asuint(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+LH_HD float pw_asfloat(uint32_t u)
+{
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+LH_HD uint64_t pw_asuint64(double f)
+{
+    uint64_t u;
+    memcpy(&u, &f, 8);
+    return u;
+}
+LH_HD double pw_asdouble(uint64_t u)
+{
+    double f;
+    memcpy(&f, &u, 8);
+    return f;
+}
+
+// 0: not an integer, 1: odd integer, 2: even integer (e_powf.c checkint)
+LH_HD int pw_checkint(uint32_t iy)
+{
+    int e = iy >> 23 & 0xff;
+    if (e < 0x7f)
+        return 0;
+    if (e > 0x7f + 23)
+        return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1))
+        return 0;
+    if (iy & (1u << (0x7f + 23 - e)))
+        return 1;
+    return 2;
+}
+
+LH_HD int pw_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000 - 1; }
+
+// Tab is anything indexable like PowfTables (host struct, LDS copy, ...)
+template <typename Tab>
+LH_HD float powf_glibc(float x, float y, const Tab &T)
+{
+    const uint32_t SIGN_BIAS = 1u << (5 + 11);
+    uint32_t sign_bias = 0;
+    uint32_t ix = pw_asuint(x), iy = pw_asuint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || pw_zeroinfnan(iy)) {
+        // Either (x < 0x1p-126 or inf or nan) or (y is 0 or inf or nan).
+        if (pw_zeroinfnan(iy)) {
+            if (2 * iy == 0)
+                return 1.0f;  // (issignaling(x) ? x + y : 1) -- value 1 or NaN; a signalling x gives NaN
+            if (ix == 0x3f800000u)
+                return 1.0f;
+            if (2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u)
+                return x + y;
+            if (2 * ix == 2 * 0x3f800000u)
+                return 1.0f;
+            if ((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u))
+                return 0.0f;  // |x|<1 && y==inf or |x|>1 && y==-inf
+            return y * y;
+        }
+        if (pw_zeroinfnan(ix)) {
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && pw_checkint(iy) == 1)
+                x2 = -x2;
+            return (iy & 0x80000000u) ? (1 / x2) : x2;
+        }
+        // x and y are non-zero finite
+        if (ix & 0x80000000u) {
+            int yint = pw_checkint(iy);
+            if (yint == 0)
+                return (x - x) / (x - x);  // __math_invalidf: NaN
+            if (yint == 1)
+                sign_bias = SIGN_BIAS;
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {
+            // normalize subnormal x so exponent becomes negative
+            ix = pw_asuint(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // ---- log2_inline(ix): log2(x) = log1p(z/c - 1)/ln2 + log2(c) + k
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    const uint32_t OFF = 0x3f330000u;
+    const uint32_t tmp = ix - OFF;
+    const int i = (tmp >> (23 - 4)) % 16;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;  // arithmetic shift
+    const double invc = T.log2_tab[i][0], logc = T.log2_tab[i][1];
+    const double z = (double)pw_asfloat(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = __builtin_fma(A0, r, A1);
+    const double p = __builtin_fma(A2, r, A3);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(A4, r, y0);
+    q = __builtin_fma(p, r2, q);
+    yy = __builtin_fma(yy, r4, q);
+    const double logx = yy;
+    const double ylogx = (double)y * logx;  // cannot overflow, y is single precision
+    if ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(126.0) >> 47)) {
+        // |y*log(x)| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6)
+            return sign_bias ? -__builtin_inff() : __builtin_inff();  // __math_oflowf
+        if (ylogx <= -150.0)
+            return sign_bias ? -0.0f : 0.0f;  // __math_uflowf
+    }
+    // ---- exp2_inline(ylogx, sign_bias): x = k/N + r, r in [-1/(2N), 1/(2N)], N = 32
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    const double SHIFT = 0x1.8p+52 / 32;
+    double kd = ylogx + SHIFT;
+    const uint64_t ki = pw_asuint64(kd);
+    kd -= SHIFT;
+    const double rr = ylogx - kd;
+    uint64_t t = T.exp2_tab[ki % 32];
+    const uint64_t ski = ki + sign_bias;
+    t += ski << (52 - 5);
+    const double s = pw_asdouble(t);
+    const double zz = __builtin_fma(C0, rr, C1);
+    const double rr2 = rr * rr;
+    double e = __builtin_fma(C2, rr, 1.0);
+    e = __builtin_fma(zz, rr2, e);
+    e = e * s;
+    return (float)e;
+}
+
+}  // namespace lh

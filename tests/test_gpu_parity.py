@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C ABI of liblumahip.so) with the CPU oracle -- needs an MI355X.
+
+Bar: integer Y/U/V planes bit-exact; decoded floats bit-exact as well (tolerance stated per test: 0 ulp,
+north_star allows 1), NaN == NaN.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden.make_golden import CONFIGS, special_frame  # noqa: E402
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7fffffff), a)
+    b = np.where(b < 0, -(b & 0x7fffffff), b)
+    return np.abs(a - b)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lumahdrv_amd
+    return lumahdrv_amd
+
+
+def table_for(o, cfg):
+    if cfg[0] in (o.PTF_PSI, o.PTF_JND_HDRVDP):
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lumahdrv_amd", "data")
+        nm = "psi" if cfg[0] == o.PTF_PSI else "jnd_hdrvdp"
+        return np.fromfile(os.path.join(d, "ptf_%s_%d.f32" % (nm, cfg[1])), dtype="<f4")
+    return None
+
+
+def pair(L, o, cfg):
+    """(HIP quantizer, oracle) for a configuration tuple (ptf, bits, cs, bitsC, maxLum, minLum)"""
+    q = L.LumaQuantizer()
+    q.setQuantizer(*cfg)
+    orc = o.Oracle(*cfg, table=table_for(o, cfg))
+    assert same_bits(q.getMapping(), orc.mapping)
+    return q, orc
+
+
+def frames(o, w, h):
+    rng = np.random.default_rng(w * 131 + h)
+    f = np.exp(rng.uniform(np.log(1e-4), np.log(3e4), size=(3, h, w))).astype(np.float32)
+    sp = special_frame(8, 16)
+    if h >= 8 and w >= 16:
+        f[:, :8, :16] = sp
+    return [f, o.synth_frame(w, h, frame=5)]
+
+
+SIZES = [(16, 8), (64, 32), (66, 34), (258, 6), (2, 2), (4, 2), (320, 180), (1280, 720)]
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+def test_encode_planes_bit_exact(L, oracle_mod, name, profile):
+    o = oracle_mod
+    cfg = CONFIGS[name]
+    q, orc = pair(L, o, cfg)
+    for (w, h) in SIZES[:6] if profile != 2 else SIZES:
+        for f in frames(o, w, h):
+            for sc in ((1.0, 20.0) if (w, h) == (64, 32) else (1.0,)):
+                planes, st, mean = q.ctx.encode_frame(f, sc, profile)
+                g = f.copy()
+                eplanes, est, eavg = orc.encode(g, sc, profile, threads=4 if w >= 320 else 1)
+                assert tuple(st) == tuple(est)
+                for p in range(3):
+                    assert np.array_equal(planes[p], eplanes[p]), (name, profile, w, h, sc, p)
+                if np.isfinite(eavg):
+                    assert mean == pytest.approx(eavg, rel=1e-3)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+def test_decode_floats_bit_exact(L, oracle_mod, name, profile):
+    o = oracle_mod
+    cfg = CONFIGS[name]
+    q, orc = pair(L, o, cfg)
+    rng = np.random.default_rng(99)
+    for (w, h) in SIZES[:7]:
+        _, hs, st, bps = L.plane_geometry(w, h, profile)
+        ws = (w, w // 2 if profile in (0, 2) else w, w // 2 if profile in (0, 2) else w)
+        planes = []
+        for p in range(3):
+            hi = (1 << cfg[1]) if (p == 0 or cfg[2] in (o.CS_RGB, o.CS_XYZ)) else (1 << cfg[3])
+            hi = min(hi + 3, 256 if bps == 1 else 65536)   # a few out-of-range codes as well
+            codes = rng.integers(0, hi, size=(hs[p], ws[p]))
+            buf = np.zeros((hs[p], st[p]), dtype=np.uint8)
+            if bps == 2:
+                buf[:, :2 * ws[p]] = codes.astype("<u2").view(np.uint8).reshape(hs[p], 2 * ws[p])
+            else:
+                buf[:, :ws[p]] = codes.astype(np.uint8)
+            planes.append(buf)
+        for sc in (1.0, 20.0):
+            got = q.ctx.decode_frame(planes, st, w, h, sc, profile)
+            exp = orc.decode(planes, st, w, h, sc, profile)
+            assert same_bits(got, exp), (name, profile, w, h, sc, int(ulp_diff(got, exp).max()))  # tolerance: 0 ulp
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("sc", [1.0, 20.0, 0.25])
+def test_transform_color_space_golden(L, oracle_mod, golden_dir, name, sc):
+    """LumaQuantizer::transformColorSpace on the GPU against the fixtures generated from the real reference"""
+    t = np.load(os.path.join(golden_dir, "ref_transform.npz"))
+    q, _ = pair(L, oracle_mod, CONFIGS[name])
+    f = t["input"].copy()
+    assert q.transformColorSpace(f, True, sc)
+    assert same_bits(f, t["%s_fwd_sc%g" % (name, sc)])
+    g = t["%s_inv_in_sc%g" % (name, sc)].copy()
+    assert q.transformColorSpace(g, False, sc)
+    assert same_bits(g, t["%s_inv_sc%g" % (name, sc)])
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_quantize_dequantize_arrays_golden(L, oracle_mod, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "ref_quantize.npz"))
+    cfg = CONFIGS[name]
+    q, _ = pair(L, oracle_mod, cfg)
+    assert np.array_equal(q.quantize(g[name + "_in0"], 0).astype(np.uint16), g[name + "_q0"])
+    assert np.array_equal(q.quantize(g[name + "_in1"], 1).astype(np.uint16), g[name + "_q1"])
+    codes = np.arange(-2, 2 ** cfg[1] + 2, dtype=np.float32)
+    assert same_bits(q.dequantize(codes, 0), g[name + "_dq0"])
+    assert same_bits(q.dequantize(np.arange(0, 2 ** cfg[3], dtype=np.float32), 1), g[name + "_dq1"])
+
+
+def test_survey_testframe_digests(L, oracle_mod):
+    """config C1 (test_simple_enc parameters on ExrInterface::testFrame): Y/U/V digests recorded from the
+    complete reference encoder"""
+    o = oracle_mod
+    q, _ = pair(L, o, CONFIGS["pq11_luv8"])
+    for (w, h, d) in [(1280, 720, ("e0ff09731298e8f6", "4c410839cf4228cc", "28868357f4a5e5e5", "db8ff401614db503")),
+                      (1920, 1080, ("ccbc4f62ce2708ab", "efe7b8578cae8ef2", "fe374dc25dde5096", "a3e03753f3d1fe44"))]:
+        f = o.test_frame(w, h)
+        planes, st, mean, tr = q.ctx.encode_frame(f, 1.0, 2, want_transformed=True)
+        assert o.survey_digest(o.packed_rows(planes[0], 2 * w)) == d[0]
+        assert o.survey_digest(o.packed_rows(planes[1], w)) == d[1]
+        assert o.survey_digest(o.packed_rows(planes[2], w)) == d[2]
+        assert o.survey_digest(tr) == d[3]   # the in-place Lu'v' floats the reference leaves in the frame
+        assert mean > 1.0
+
+
+def test_literal_and_global_lut_modes(L, oracle_mod):
+    """a non-monotone table must take the literal bisection path, a 13-bit table the global-memory path;
+    both still bit-exact against the oracle's (literal) search"""
+    o = oracle_mod
+    rng = np.random.default_rng(5)
+    # (a) non-monotone 11-bit table, as a decoder may be handed in attachment 434
+    q = L.LumaQuantizer()
+    lut = L.build_lut(L.PTF_PQ, 11).copy()
+    lut[700:720] = lut[700:720][::-1]
+    lut[5] = lut[4]
+    q.setQuantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, mapping_override=lut)
+    assert q.ctx.quantizer_info()["mode"] == 0
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    orc.overwrite_mapping(lut)
+    f = frames(o, 64, 32)[0]
+    planes, st, _ = q.ctx.encode_frame(f, 1.0, 2)
+    e, _, _ = orc.encode(f.copy(), 1.0, 2)
+    assert all(np.array_equal(a, b) for a, b in zip(planes, e))
+    assert same_bits(q.ctx.decode_frame(planes, st, 64, 32, 1.0, 2), orc.decode(e, st, 64, 32, 1.0, 2))
+    # (b) 13-bit PQ table: does not fit the LDS budget -> global-memory bisection
+    q2 = L.LumaQuantizer()
+    q2.setQuantizer(L.PTF_PQ, 13, L.CS_XYZ, 8, 1e4, 0.005)
+    assert q2.ctx.quantizer_info()["mode"] == 2
+    orc2 = o.Oracle(o.PTF_PQ, 13, o.CS_XYZ, 8, 1e4, 0.005)
+    for profile in (2, 3):
+        planes, st, _ = q2.ctx.encode_frame(f, 1.0, profile)
+        e, _, _ = orc2.encode(f.copy(), 1.0, profile)
+        assert all(np.array_equal(a, b) for a, b in zip(planes, e))
+        assert same_bits(q2.ctx.decode_frame(planes, st, 64, 32, 1.0, profile), orc2.decode(e, st, 64, 32, 1.0, profile))
+    # the default tables take the bucketed path
+    q3 = L.LumaQuantizer()
+    q3.setQuantizer(*CONFIGS["pq11_luv8"])
+    info = q3.ctx.quantizer_info()
+    assert info["mode"] == 1 and info["steps"] <= 2
+
+
+def test_unaligned_strides_and_bad_arguments(L, oracle_mod):
+    o = oracle_mod
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    f = frames(o, 66, 34)[0]
+    # odd strides force the byte-store path
+    planes, st, _ = q.ctx.encode_frame(f, 1.0, 2, strides=(66 * 2 + 3, 33 * 2 + 1, 33 * 2 + 5))
+    g = f.copy()
+    orc.transform(g, True, 1.0)
+    for p in range(3):
+        w = 66 if p == 0 else 33
+        h = 34 if p == 0 else 17
+        ref = np.zeros((h, st[p]), dtype=np.uint8)
+        orc.L.lo_pack_plane(__import__("ctypes").byref(orc.q), g[p].ctypes.data, p, 2, 66, 34, ref.ctypes.data, st[p], None)
+        assert np.array_equal(planes[p][:, :2 * w], ref[:, :2 * w])
+    with pytest.raises(L.LumaHipError):      # "Invalid frame size", src/luma_encoder.cpp:118-119
+        q.ctx.encode_frame(np.zeros((3, 5, 8), dtype=np.float32), 1.0, 2)
+    with pytest.raises(L.LumaHipError):
+        q.ctx.encode_frame(np.zeros((3, 4, 8), dtype=np.float32), 1.0, 7)
+    bad = L.LumaQuantizer()
+    bad.setQuantizer(L.PTF_PQ, 11, 9, 8, 1e4, 0.005)   # unknown colour space: transformColorSpace returns false
+    assert bad.transformColorSpace(np.ones((3, 2, 2), dtype=np.float32), True, 1.0) is False
+
+
+def test_full_size_4k_frame_and_properties(L, oracle_mod):
+    """BASELINE configs[1] size: one full 3840x2160 frame bit-exact against the (8-thread) oracle, plus
+    size-independent properties: synthetic generator parity, launch-geometry independence, and
+    encode(decode(planes)) luma idempotence."""
+    import torch
+    o = oracle_mod
+    w, h = 3840, 2160
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    dev = torch.device("cuda:0")
+    n3 = 3 * w * h
+    src = torch.empty(2 * n3, dtype=torch.float32, device=dev)
+    q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    q.ctx.synth_frames_device(src.data_ptr(), n3, 2, w, h, 20250929, 7)
+    torch.cuda.synchronize()
+    host = src[:n3].cpu().numpy().reshape(3, h, w)
+    assert same_bits(host, o.synth_frame(w, h, 20250929, 7))           # device generator == oracle generator
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    sizes = [hs[p] * st[p] for p in range(3)]
+    planes = [torch.zeros(2 * sizes[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    stats = torch.zeros(6, dtype=torch.float32, device=dev)
+    q.ctx.encode_frames_device(src.data_ptr(), n3, 2, w, h, 1.0, 2, [p.data_ptr() for p in planes], st, sizes,
+                               stats.data_ptr())
+    torch.cuda.synchronize()
+    got = [planes[p][:sizes[p]].cpu().numpy().reshape(hs[p], st[p]) for p in range(3)]
+    e, _, avg = orc.encode(host.copy(), 1.0, 2, threads=8)
+    for p in range(3):
+        assert np.array_equal(got[p], e[p]), p
+    s = stats.cpu().numpy()
+    assert s[0] / (w * h) == pytest.approx(avg, rel=1e-3) and s[1] >= 1e-4 and s[2] <= 1e8
+    # decode on device, compare full frame with the oracle (0 ulp)
+    out = torch.empty(2 * n3, dtype=torch.float32, device=dev)
+    q.ctx.decode_frames_device([p.data_ptr() for p in planes], st, sizes, 2, w, h, 2, 1.0, out.data_ptr(), n3)
+    torch.cuda.synchronize()
+    dec = out[:n3].cpu().numpy().reshape(3, h, w)
+    assert same_bits(dec, orc.decode(e, st, w, h, 1.0, 2, threads=8))
+    # idempotence: re-encoding the decoded frame reproduces every luma code whose decoded colour is in gamut
+    planes2 = [torch.zeros(2 * sizes[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    q.ctx.encode_frames_device(out.data_ptr(), n3, 2, w, h, 1.0, 2, [p.data_ptr() for p in planes2], st, sizes)
+    torch.cuda.synchronize()
+    y1 = planes[0][:sizes[0]].cpu().numpy().view("<u2").astype(np.int32)
+    y2 = planes2[0][:sizes[0]].cpu().numpy().view("<u2").astype(np.int32)
+    assert np.mean(np.abs(y1 - y2) <= 1) > 0.999
+    q.ctx.set_stream(None)

@@ -1,0 +1,70 @@
+// tools/verify_powf.cpp -- exhaustive check of lumahdrv_amd/csrc/pow_glibc.hpp against the host libm.
+//
+//   g++ -O2 -ffp-contract=off -std=c++17 -pthread -o /tmp/verify_powf tools/verify_powf.cpp -lm && /tmp/verify_powf [stride]
+//
+// For each of the four exponents the reference's transformPQ uses (src/luma_quantizer.cpp:485-501:
+// n = 0.1593f, m = 78.8438f, 1.0f/m, 1.0f/n) every non-negative float bit pattern 0 .. 0x7f800000 (zero,
+// subnormals, normals, +inf) plus NaNs and a sweep of negatives is evaluated with the restatement and
+// with libm powf; results must be bit-identical (NaN == NaN).  stride > 1 samples every stride-th pattern.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../lumahdrv_amd/csrc/pow_glibc.hpp"
+
+static inline bool same(float a, float b)
+{
+    if (a != a && b != b)
+        return true;
+    uint32_t x, y;
+    memcpy(&x, &a, 4);
+    memcpy(&y, &b, 4);
+    return x == y;
+}
+
+int main(int argc, char **argv)
+{
+    const uint64_t stride = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+    const float m = 78.8438, n = 0.1593;
+    volatile float one = 1.0f;
+    const float ys[4] = {n, m, one / m, one / n};
+    const unsigned nt = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4;
+    uint64_t total_bad = 0, total = 0;
+    for (int e = 0; e < 4; e++) {
+        const float y = ys[e];
+        std::atomic<uint64_t> bad{0}, cnt{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                uint64_t b = 0, c = 0;
+                for (uint64_t u = t * stride; u <= 0xffffffffull; u += nt * stride) {
+                    // all non-negative patterns; of the negative / NaN half only every 4096th
+                    if (u > 0x7f800000ull && (u & 0xfff) != 0 && stride == 1)
+                        continue;
+                    float x = lh::pw_asfloat((uint32_t)u);
+                    float a = lh::powf_glibc(x, y, lh::kPowfTablesHost);
+                    float r = powf(x, y);
+                    c++;
+                    if (!same(a, r)) {
+                        if (b < 5)
+                            fprintf(stderr, "MISMATCH y=%a x=%a (0x%08x): restated %a libm %a\n", y, x, (unsigned)u, a, r);
+                        b++;
+                    }
+                }
+                bad += b;
+                cnt += c;
+            });
+        for (auto &x : th)
+            x.join();
+        printf("y=%-14a (%.9g): %llu arguments, %llu mismatches\n", y, y, (unsigned long long)cnt.load(),
+               (unsigned long long)bad.load());
+        total_bad += bad;
+        total += cnt;
+    }
+    printf("TOTAL %llu arguments, %llu mismatches\n", (unsigned long long)total, (unsigned long long)total_bad);
+    return total_bad ? 1 : 0;
+}
