@@ -69,6 +69,23 @@ LH_DEV float div_nr_r(float a, float b, float r1)
 LH_DEV float div_nr(float a, float b) { return div_nr_r(a, b, rcp_nr(b)); }
 #endif
 
+// a / 255.0f in three operations (Markstein): q = a*RN(1/255); r = fma(-255,q,a); q' = fma(r,RN(1/255),q).
+// Verified exhaustively against fp32 division over all 2^32 bit patterns of a (tools/verify_constdiv.c):
+// bit-identical except a = -0 (gives +0) and a = +-inf (gives NaN).  Licensed only where a > 0, finite
+// or NaN.  The same construction is NOT exact for 410, 224, 1.8814f, 1.4746f, 0.6780f (checked), so those
+// divisors keep div_ieee.
+LH_DEV float div_255_pos(float a)
+{
+#ifdef LH_NO_FAST_DIV
+    return a / 255.0f;
+#else
+    const float rc = 1.0f / 255.0f;  // 0x1.010102p-8, constant-folded, correctly rounded
+    const float q = a * rc;
+    const float r = __builtin_fmaf(-255.0f, q, a);
+    return __builtin_fmaf(r, rc, q);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Colour transforms, one pixel.  in: r,g,b (already multiplied by nothing); out: the three channel
 // values the reference stores back into the frame.
@@ -128,8 +145,9 @@ LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, f
     const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
     const float rd = rcp_nr(den);
     c0 = Y;
-    c1 = div_ieee(div_nr_r(4.0f * x, den, rd) * 410.f, 255.0f);
-    c2 = div_ieee(div_nr_r(9.0f * y, den, rd) * 410.f, 255.0f);
+    // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410 (or NaN): div_255_pos is exact
+    c1 = div_255_pos(div_nr_r(4.0f * x, den, rd) * 410.f);
+    c2 = div_255_pos(div_nr_r(9.0f * y, den, rd) * 410.f);
 }
 
 template <>
@@ -268,38 +286,100 @@ LH_DEV int quantize_lut_literal(float v, LutPtr lut, int maxVal)
     return ((v - lut[l]) < (lut[r] - v)) ? l : r;
 }
 
-template <int N, typename LutPtr, typename BucketPtr>
+// Bucketed search (see lut_index.hpp).  `bucket[k]` holds the BYTE offset (4*start) of the first candidate
+// entry of key k; the table is followed by NaN padding, so probes past maxVal compare false and
+// lut[maxVal+1] reads NaN.  Result for every v (NaN, +-inf, negatives, denormals included) equals the
+// reference's bisection + nearest-of-two (src/luma_quantizer.cpp:222-235):
+//   * l = start + (number of further entries <= v)  -- unclamped, so l == maxVal when v >= map[maxVal];
+//     then mr = NaN, the nearest test is false, code = maxVal+1, and the final min() gives maxVal, which
+//     is what the reference returns (l = maxVal-1, r = maxVal, "v - map[l] < map[r] - v" is false);
+//   * NaN: every `v < map[m]` of the reference is false, so it returns maxVal; here l is forced to maxVal.
+// STEPS >= 0: compile-time number of refinement probes; STEPS < 0: q.steps at run time.
+LH_DEV float lds_f32(const float *lut, int byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut) + byte_off);
+}
+
+template <int N, int STEPS, typename LutPtr, typename BucketPtr>
 LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
 {
-    int l[N];
+    int l4[N];
+    const int maxVal4 = q.maxVal * 4;
 #pragma unroll
     for (int i = 0; i < N; i++) {
         int k = (__float_as_int(v[i]) >> q.shift) - q.kmin;
         k = min(max(k, 0), q.nbuckets - 1);
-        l[i] = bucket[k];
+        l4[i] = bucket[k];
     }
-    for (int s = q.steps - 1; s >= 0; --s) {
-        const int step = 1 << s;
+    if constexpr (STEPS == 1) {
+        // one refinement probe: fetch map[l], map[l+1], map[l+2] at once and select
+        float a[N], b[N], c[N];
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            const int c = l[i] + step;
-            l[i] = (lut[c] <= v[i]) ? c : l[i];
+            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
+            a[i] = lds_f32(lut, l4[i]);
+            b[i] = lds_f32(lut, l4[i] + 4);
+            c[i] = lds_f32(lut, l4[i] + 8);
         }
-    }
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int ll = min(l[i], q.maxVal - 1);
-        const float ml = lut[ll], mr = lut[ll + 1];
-        int c = ((v[i] - ml) < (mr - v[i])) ? ll : ll + 1;
-        code[i] = (v[i] != v[i]) ? q.maxVal : c;  // bisection with NaN: every `v < map[m]` is false
+        for (int i = 0; i < N; i++) {
+            const bool t = (b[i] <= v[i]);
+            const float ml = t ? b[i] : a[i];
+            const float mr = t ? c[i] : b[i];
+            const int l = (l4[i] >> 2) + (t ? 1 : 0);
+            const int cc = ((v[i] - ml) < (mr - v[i])) ? l : l + 1;
+            code[i] = min(cc, q.maxVal);
+        }
+    } else {
+        if constexpr (STEPS >= 0) {
+#pragma unroll
+            for (int s = STEPS - 1; s >= 0; --s) {
+                float m[N];
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    m[i] = lds_f32(lut, l4[i] + (4 << s));
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    l4[i] = (m[i] <= v[i]) ? l4[i] + (4 << s) : l4[i];
+            }
+        } else {
+            for (int s = q.steps - 1; s >= 0; --s) {
+                float m[N];
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    m[i] = lds_f32(lut, l4[i] + (4 << s));
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    l4[i] = (m[i] <= v[i]) ? l4[i] + (4 << s) : l4[i];
+            }
+        }
+        float ml[N], mr[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
+            ml[i] = lds_f32(lut, l4[i]);
+            mr[i] = lds_f32(lut, l4[i] + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int l = l4[i] >> 2;
+            const int cc = ((v[i] - ml[i]) < (mr[i] - v[i])) ? l : l + 1;
+            code[i] = min(cc, q.maxVal);
+        }
     }
 }
 
+// MODE: 0 literal bisection (LDS), 2 literal bisection (global), 1 bucketed with run-time step count,
+//       11 / 12 bucketed with 1 / 2 compile-time steps
 template <int MODE, int N, typename LutPtr, typename BucketPtr>
 LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
 {
     if constexpr (MODE == 1) {
-        quantize_lut_bucket<N>(v, code, lut, bucket, q);
+        quantize_lut_bucket<N, -1>(v, code, lut, bucket, q);
+    } else if constexpr (MODE == 11) {
+        quantize_lut_bucket<N, 1>(v, code, lut, bucket, q);
+    } else if constexpr (MODE == 12) {
+        quantize_lut_bucket<N, 2>(v, code, lut, bucket, q);
     } else {
 #pragma unroll
         for (int i = 0; i < N; i++)

@@ -96,6 +96,20 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, bool lut_in_lds
 }
 
 // ---- sample stores / loads ------------------------------------------------------------------------
+// Every frame byte is touched exactly once, so all global accesses of the pixel stream are non-temporal
+// (`nt`): measured +4-5 % on the encode access pattern (tools/membench2.hip, profiles/r01_membench.txt).
+typedef float lh_v4f __attribute__((ext_vector_type(4)));
+typedef float lh_v2f __attribute__((ext_vector_type(2)));
+typedef unsigned lh_v2u __attribute__((ext_vector_type(2)));
+
+LH_DEV void nt_store_u32x2(void *p, uint32_t a, uint32_t b)
+{
+    lh_v2u t = {a, b};
+    __builtin_nontemporal_store(t, reinterpret_cast<lh_v2u *>(p));
+}
+LH_DEV void nt_store_u32(void *p, uint32_t a) { __builtin_nontemporal_store(a, reinterpret_cast<uint32_t *>(p)); }
+LH_DEV void nt_store_u16(void *p, uint16_t a) { __builtin_nontemporal_store(a, reinterpret_cast<uint16_t *>(p)); }
+LH_DEV void nt_store_u8(void *p, unsigned char a) { __builtin_nontemporal_store(a, reinterpret_cast<unsigned char *>(p)); }
 
 // N consecutive samples (codes) at p; bps 1 or 2; little-endian 16-bit exactly as
 // src/luma_encoder.cpp:301-307 produces (bl = res/256 at +1, bh = res - bl*256 at +0); the 8-bit path
@@ -106,14 +120,12 @@ LH_DEV void store_samples(unsigned char *p, const int (&c)[N], int bps, int alig
     if (bps == 2) {
         if (aligned) {
             if constexpr (N == 4) {
-                uint2 v;
-                v.x = (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16);
-                v.y = (uint32_t)(c[2] & 0xffff) | ((uint32_t)c[3] << 16);
-                *reinterpret_cast<uint2 *>(p) = v;
+                nt_store_u32x2(p, (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16),
+                               (uint32_t)(c[2] & 0xffff) | ((uint32_t)c[3] << 16));
             } else if constexpr (N == 2) {
-                *reinterpret_cast<uint32_t *>(p) = (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16);
+                nt_store_u32(p, (uint32_t)(c[0] & 0xffff) | ((uint32_t)c[1] << 16));
             } else {
-                *reinterpret_cast<uint16_t *>(p) = (uint16_t)c[0];
+                nt_store_u16(p, (uint16_t)c[0]);
             }
         } else {
 #pragma unroll
@@ -125,12 +137,12 @@ LH_DEV void store_samples(unsigned char *p, const int (&c)[N], int bps, int alig
     } else {
         if (aligned) {
             if constexpr (N == 4) {
-                *reinterpret_cast<uint32_t *>(p) = (uint32_t)(c[0] & 0xff) | ((uint32_t)(c[1] & 0xff) << 8) |
-                                                   ((uint32_t)(c[2] & 0xff) << 16) | ((uint32_t)(c[3] & 0xff) << 24);
+                nt_store_u32(p, (uint32_t)(c[0] & 0xff) | ((uint32_t)(c[1] & 0xff) << 8) |
+                                    ((uint32_t)(c[2] & 0xff) << 16) | ((uint32_t)(c[3] & 0xff) << 24));
             } else if constexpr (N == 2) {
-                *reinterpret_cast<uint16_t *>(p) = (uint16_t)((c[0] & 0xff) | ((c[1] & 0xff) << 8));
+                nt_store_u16(p, (uint16_t)((c[0] & 0xff) | ((c[1] & 0xff) << 8)));
             } else {
-                p[0] = (unsigned char)(c[0] & 0xff);
+                nt_store_u8(p, (unsigned char)(c[0] & 0xff));
             }
         } else {
 #pragma unroll
@@ -147,13 +159,13 @@ LH_DEV void load_samples(const unsigned char *p, int (&c)[N], int bps, int align
     if (bps == 2) {
         if (aligned) {
             if constexpr (N == 4) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(p);
+                const lh_v2u v = __builtin_nontemporal_load(reinterpret_cast<const lh_v2u *>(p));
                 c[0] = v.x & 0xffff; c[1] = v.x >> 16; c[2] = v.y & 0xffff; c[3] = v.y >> 16;
             } else if constexpr (N == 2) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
                 c[0] = v & 0xffff; c[1] = v >> 16;
             } else {
-                c[0] = *reinterpret_cast<const uint16_t *>(p);
+                c[0] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(p));
             }
         } else {
 #pragma unroll
@@ -163,10 +175,10 @@ LH_DEV void load_samples(const unsigned char *p, int (&c)[N], int bps, int align
     } else {
         if (aligned) {
             if constexpr (N == 4) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
                 c[0] = v & 0xff; c[1] = (v >> 8) & 0xff; c[2] = (v >> 16) & 0xff; c[3] = v >> 24;
             } else if constexpr (N == 2) {
-                const uint32_t v = *reinterpret_cast<const uint16_t *>(p);
+                const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(p));
                 c[0] = v & 0xff; c[1] = v >> 8;
             } else {
                 c[0] = p[0];
@@ -183,10 +195,10 @@ template <int VW>
 LH_DEV void load_px(const float *p, float (&v)[VW])
 {
     if constexpr (VW == 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(p);
+        const lh_v4f t = __builtin_nontemporal_load(reinterpret_cast<const lh_v4f *>(p));
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
-        const float2 t = *reinterpret_cast<const float2 *>(p);
+        const lh_v2f t = __builtin_nontemporal_load(reinterpret_cast<const lh_v2f *>(p));
         v[0] = t.x; v[1] = t.y;
     }
 }
@@ -195,9 +207,11 @@ template <int VW>
 LH_DEV void store_px(float *p, const float (&v)[VW])
 {
     if constexpr (VW == 4) {
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        const lh_v4f t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<lh_v4f *>(p));
     } else {
-        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+        const lh_v2f t = {v[0], v[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<lh_v2f *>(p));
     }
 }
 
@@ -211,21 +225,166 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 
 // ---- ENCODE ---------------------------------------------------------------------------------------
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
-// LM: LUT search mode (lh::LutMode).
+// LM: LUT search mode (0 literal/LDS, 2 literal/global, 1 bucketed run-time steps, 11/12 bucketed 1/2 steps).
+//
+// Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued before the current
+// unit is processed, so every wave keeps 6 KiB of HBM reads in flight while it computes (without this the
+// kernel sat at ~45 % SQ_WAIT_ANY, profiles/r01_pmc_summary.md).
+
+template <int VW>
+struct EncUnit {
+    float in[3][2][VW];
+    int f, ux, uy;
+    bool valid;
+};
+
+template <int VW>
+LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, int NW, size_t cs)
+{
+    u.valid = false;
+    if (t >= a.g.totalTiles)
+        return;
+    int bx, by;
+    tile_coords(t, a.g, u.f, bx, by);
+    u.ux = bx * 64 + tx;
+    u.uy = by * NW + ty;
+    if (u.ux >= a.g.unitsX || u.uy >= a.g.unitsY)
+        return;
+    u.valid = true;
+    const float *p = a.src + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        load_px<VW>(p + c * cs, u.in[c][0]);
+        load_px<VW>(p + c * cs + a.g.w, u.in[c][1]);
+    }
+}
+
+struct EncStats {
+    float sum, mn, mx;
+    int frame;
+};
+
+LH_DEV void stats_flush(EncStats &st, float *stats, int tx)
+{
+    if (st.frame >= 0) {
+        const float s = wave_sum(st.sum), mn = wave_min(st.mn), mx = wave_max(st.mx);
+        if (tx == 0) {
+            atomicAdd(&stats[3 * st.frame + 0], s);
+            atomicMin(&stats[3 * st.frame + 1], mn);
+            atomicMax(&stats[3 * st.frame + 2], mx);
+        }
+    }
+    st.sum = 0.0f;
+    st.mn = __builtin_inff();
+    st.mx = -__builtin_inff();
+}
+
+template <int CS, bool SUB, int VW, int LM, typename LutPtr>
+LH_DEV void enc_process(const EncUnit<VW> &u, const EncArgs &a, const XformConst &k, LutPtr lut,
+                        const uint16_t *s_bucket, EncStats &st)
+{
+    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
+    const float maxC = a.q.maxC;
+    const int f = u.f, ux = u.ux, uy = u.uy;
+    // colour transform (row-major pixel order inside the unit: j = r*VW + i)
+    float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < VW; i++)
+            xform_fwd<CS>(u.in[0][r][i], u.in[1][r][i], u.in[2][r][i], k, c0[r * VW + i], c1[r * VW + i], c2[r * VW + i]);
+
+    if (a.stats) {
+#pragma unroll
+        for (int j = 0; j < 2 * VW; j++) {
+            st.sum += c0[j];
+            st.mn = fminf(st.mn, c0[j]);
+            st.mx = fmaxf(st.mx, c0[j]);
+        }
+    }
+
+    // plane 0
+    int code0[2 * VW];
+    quantize_lut<LM, 2 * VW>(c0, code0, lut, s_bucket, a.q);
+    {
+        unsigned char *d = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
+                           (size_t)ux * VW * a.bps;
+        int row[VW];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                row[i] = code0[r * VW + i];
+            store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
+        }
+    }
+
+    // planes 1, 2
+    if constexpr (SUB) {
+        constexpr int NQ = VW / 2;
+        float a1[NQ], a2[NQ];
+#pragma unroll
+        for (int qd = 0; qd < NQ; qd++) {
+            // src/luma_encoder.cpp:287-289: 0.25f*(src[i] + src[i+1] + src[i+2w] + src[i+2w+1])
+            a1[qd] = 0.25f * (((c1[2 * qd] + c1[2 * qd + 1]) + c1[VW + 2 * qd]) + c1[VW + 2 * qd + 1]);
+            a2[qd] = 0.25f * (((c2[2 * qd] + c2[2 * qd + 1]) + c2[VW + 2 * qd]) + c2[VW + 2 * qd + 1]);
+        }
+        int k1[NQ], k2[NQ];
+        if constexpr (LUT_ALL) {
+            quantize_lut<LM, NQ>(a1, k1, lut, s_bucket, a.q);
+            quantize_lut<LM, NQ>(a2, k2, lut, s_bucket, a.q);
+        } else {
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++) {
+                k1[qd] = quantize_color(a1[qd], maxC);
+                k2[qd] = quantize_color(a2[qd], maxC);
+            }
+        }
+        store_samples<NQ>(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] +
+                              (size_t)ux * NQ * a.bps, k1, a.bps, a.aligned);
+        store_samples<NQ>(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] +
+                              (size_t)ux * NQ * a.bps, k2, a.bps, a.aligned);
+    } else {
+        int k1[2 * VW], k2[2 * VW];
+        if constexpr (LUT_ALL) {
+            quantize_lut<LM, 2 * VW>(c1, k1, lut, s_bucket, a.q);
+            quantize_lut<LM, 2 * VW>(c2, k2, lut, s_bucket, a.q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * VW; j++) {
+                k1[j] = quantize_color(c1[j], maxC);
+                k2[j] = quantize_color(c2[j], maxC);
+            }
+        }
+#pragma unroll
+        for (int pl = 1; pl < 3; pl++) {
+            unsigned char *d = a.dst[pl] + (size_t)f * a.dst_frame_stride[pl] + (size_t)(2 * uy) * a.stride[pl] +
+                               (size_t)ux * VW * a.bps;
+            int row[VW];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    row[i] = (pl == 1) ? k1[r * VW + i] : k2[r * VW + i];
+                store_samples<VW>(d + (size_t)r * a.stride[pl], row, a.bps, a.aligned);
+            }
+        }
+    }
+}
+
 template <int CS, bool SUB, int VW, int LM>
 __global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool LUT_LDS = (LM != 2);
-    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
+    constexpr bool BUCKETED = (LM == 1 || LM == 11 || LM == 12);
     stage_tables<true>(smem, a.q, LUT_LDS, CS == CS_YCBCR);
 
     const float *s_lut = reinterpret_cast<const float *>(smem);
     const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
-    const float *lut = LUT_LDS ? s_lut : a.q.lut;
     int pw_off = 0;
     if (LUT_LDS)
-        pw_off = lds_lut_bytes(a.q) + ((LM == 1) ? lds_bucket_bytes(a.q) : 0);
+        pw_off = lds_lut_bytes(a.q) + (BUCKETED ? lds_bucket_bytes(a.q) : 0);
     XformConst k;
     k.sc = a.sc;
     k.Lmax = a.q.Lmax;
@@ -234,142 +393,143 @@ __global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
     const size_t cs = (size_t)a.g.w * a.g.h;  // channel stride (floats)
-    const float maxC = a.q.maxC;
+    const int G = gridDim.x;
 
-    float st_sum = 0.0f, st_min = __builtin_inff(), st_max = -__builtin_inff();
-    int st_frame = -1;
+    EncStats st;
+    st.frame = -1;
+    st.sum = 0.0f;
+    st.mn = __builtin_inff();
+    st.mx = -__builtin_inff();
 
-    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
-        int f, bx, by;
-        tile_coords(t, a.g, f, bx, by);
-        if (a.stats && f != st_frame) {
-            if (st_frame >= 0) {
-                const float s = wave_sum(st_sum), mn = wave_min(st_min), mx = wave_max(st_max);
-                if (tx == 0) {
-                    atomicAdd(&a.stats[3 * st_frame + 0], s);
-                    atomicMin(&a.stats[3 * st_frame + 1], mn);
-                    atomicMax(&a.stats[3 * st_frame + 2], mx);
-                }
+    EncUnit<VW> cur, nxt;
+    enc_load<VW>(cur, a, blockIdx.x, tx, ty, NW, cs);
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
+        enc_load<VW>(nxt, a, t + G, tx, ty, NW, cs);  // prefetch: in flight while `cur` is processed
+        if (a.stats) {
+            const int f = t / a.g.tilesPerFrame;  // wave-uniform
+            if (f != st.frame) {
+                stats_flush(st, a.stats, tx);
+                st.frame = f;
             }
-            st_sum = 0.0f; st_min = __builtin_inff(); st_max = -__builtin_inff();
-            st_frame = f;
         }
-        const int ux = bx * 64 + tx, uy = by * NW + ty;
-        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
-            continue;
+        if (cur.valid) {
+            if constexpr (LUT_LDS)
+                enc_process<CS, SUB, VW, LM>(cur, a, k, s_lut, s_bucket, st);
+            else
+                enc_process<CS, SUB, VW, LM>(cur, a, k, a.q.lut, s_bucket, st);
+        }
+        cur = nxt;
+    }
+    if (a.stats)
+        stats_flush(st, a.stats, tx);
+}
 
-        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * VW;
-        float in[3][2][VW];
+// ---- DECODE ---------------------------------------------------------------------------------------
+// GL: LUT read from global memory (bitdepth > 12) instead of LDS.  Same software pipeline as encode: the
+// sample loads of the next unit are issued before the current unit is dequantized and transformed.
+template <bool SUB, int VW>
+struct DecUnit {
+    int y[2][VW];
+    int c1[SUB ? VW / 2 : 2 * VW];
+    int c2[SUB ? VW / 2 : 2 * VW];
+    int f, ux, uy;
+    bool valid;
+};
+
+template <bool SUB, int VW>
+LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int ty, int NW)
+{
+    u.valid = false;
+    if (t >= a.g.totalTiles)
+        return;
+    int bx, by;
+    tile_coords(t, a.g, u.f, bx, by);
+    u.ux = bx * 64 + tx;
+    u.uy = by * NW + ty;
+    if (u.ux >= a.g.unitsX || u.uy >= a.g.unitsY)
+        return;
+    u.valid = true;
+    const int f = u.f, ux = u.ux, uy = u.uy;
+    {
+        const unsigned char *s = a.src[0] + (size_t)f * a.src_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
+                                 (size_t)ux * VW * a.bps;
+        load_samples<VW>(s, u.y[0], a.bps, a.aligned);
+        load_samples<VW>(s + a.stride[0], u.y[1], a.bps, a.aligned);
+    }
+    if constexpr (SUB) {
+        constexpr int NQ = VW / 2;
+        load_samples<NQ>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * NQ * a.bps,
+                         u.c1, a.bps, a.aligned);
+        load_samples<NQ>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * NQ * a.bps,
+                         u.c2, a.bps, a.aligned);
+    } else {
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            load_px<VW>(p + c * cs, in[c][0]);
-            load_px<VW>(p + c * cs + a.g.w, in[c][1]);
-        }
-        // colour transform (row-major pixel order inside the unit: j = r*VW + i)
-        float c0[2 * VW], c1[2 * VW], c2[2 * VW];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 2; r++) {
+            int row[VW];
+            load_samples<VW>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)(2 * uy + r) * a.stride[1] +
+                                 (size_t)ux * VW * a.bps, row, a.bps, a.aligned);
 #pragma unroll
             for (int i = 0; i < VW; i++)
-                xform_fwd<CS>(in[0][r][i], in[1][r][i], in[2][r][i], k, c0[r * VW + i], c1[r * VW + i], c2[r * VW + i]);
-
-        if (a.stats) {
+                u.c1[r * VW + i] = row[i];
+            load_samples<VW>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)(2 * uy + r) * a.stride[2] +
+                                 (size_t)ux * VW * a.bps, row, a.bps, a.aligned);
 #pragma unroll
-            for (int j = 0; j < 2 * VW; j++) {
-                st_sum += c0[j];
-                st_min = fminf(st_min, c0[j]);
-                st_max = fmaxf(st_max, c0[j]);
-            }
-        }
-
-        // plane 0
-        int code0[2 * VW];
-        quantize_lut<LM, 2 * VW>(c0, code0, lut, s_bucket, a.q);
-        {
-            unsigned char *d = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
-                               (size_t)ux * VW * a.bps;
-            int row[VW];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-#pragma unroll
-                for (int i = 0; i < VW; i++)
-                    row[i] = code0[r * VW + i];
-                store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
-            }
-        }
-
-        // planes 1, 2
-        if constexpr (SUB) {
-            constexpr int NQ = VW / 2;
-            float a1[NQ], a2[NQ];
-#pragma unroll
-            for (int qd = 0; qd < NQ; qd++) {
-                // src/luma_encoder.cpp:287-289: 0.25f*(src[i] + src[i+1] + src[i+2w] + src[i+2w+1])
-                a1[qd] = 0.25f * (((c1[2 * qd] + c1[2 * qd + 1]) + c1[VW + 2 * qd]) + c1[VW + 2 * qd + 1]);
-                a2[qd] = 0.25f * (((c2[2 * qd] + c2[2 * qd + 1]) + c2[VW + 2 * qd]) + c2[VW + 2 * qd + 1]);
-            }
-            int k1[NQ], k2[NQ];
-            if constexpr (LUT_ALL) {
-                quantize_lut<LM, NQ>(a1, k1, lut, s_bucket, a.q);
-                quantize_lut<LM, NQ>(a2, k2, lut, s_bucket, a.q);
-            } else {
-#pragma unroll
-                for (int qd = 0; qd < NQ; qd++) {
-                    k1[qd] = quantize_color(a1[qd], maxC);
-                    k2[qd] = quantize_color(a2[qd], maxC);
-                }
-            }
-            store_samples<NQ>(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] +
-                                  (size_t)ux * NQ * a.bps, k1, a.bps, a.aligned);
-            store_samples<NQ>(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] +
-                                  (size_t)ux * NQ * a.bps, k2, a.bps, a.aligned);
-        } else {
-            int k1[2 * VW], k2[2 * VW];
-            if constexpr (LUT_ALL) {
-                quantize_lut<LM, 2 * VW>(c1, k1, lut, s_bucket, a.q);
-                quantize_lut<LM, 2 * VW>(c2, k2, lut, s_bucket, a.q);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2 * VW; j++) {
-                    k1[j] = quantize_color(c1[j], maxC);
-                    k2[j] = quantize_color(c2[j], maxC);
-                }
-            }
-#pragma unroll
-            for (int pl = 1; pl < 3; pl++) {
-                unsigned char *d = a.dst[pl] + (size_t)f * a.dst_frame_stride[pl] + (size_t)(2 * uy) * a.stride[pl] +
-                                   (size_t)ux * VW * a.bps;
-                int row[VW];
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-#pragma unroll
-                    for (int i = 0; i < VW; i++)
-                        row[i] = (pl == 1) ? k1[r * VW + i] : k2[r * VW + i];
-                    store_samples<VW>(d + (size_t)r * a.stride[pl], row, a.bps, a.aligned);
-                }
-            }
-        }
-    }
-    if (a.stats && st_frame >= 0) {
-        const float s = wave_sum(st_sum), mn = wave_min(st_min), mx = wave_max(st_max);
-        if (tx == 0) {
-            atomicAdd(&a.stats[3 * st_frame + 0], s);
-            atomicMin(&a.stats[3 * st_frame + 1], mn);
-            atomicMax(&a.stats[3 * st_frame + 2], mx);
+            for (int i = 0; i < VW; i++)
+                u.c2[r * VW + i] = row[i];
         }
     }
 }
 
-// ---- DECODE ---------------------------------------------------------------------------------------
-// GL: LUT read from global memory (bitdepth > 12) instead of LDS
+template <int CS, bool SUB, int VW, typename LutPtr>
+LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, size_t cs)
+{
+    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
+    const float maxC = a.q.maxC;
+    const int maxVal = a.q.maxVal;
+    float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < VW; i++)
+            c0[r * VW + i] = dequantize_lut(u.y[r][i], lut, maxVal);
+    if constexpr (SUB) {
+        constexpr int NQ = VW / 2;
+#pragma unroll
+        for (int qd = 0; qd < NQ; qd++) {
+            const float v1 = LUT_ALL ? dequantize_lut(u.c1[qd], lut, maxVal) : dequantize_color(u.c1[qd], maxC);
+            const float v2 = LUT_ALL ? dequantize_lut(u.c2[qd], lut, maxVal) : dequantize_color(u.c2[qd], maxC);
+            // src/luma_decoder.cpp:229-234: the sample is replicated to its 2x2 block
+            c1[2 * qd] = c1[2 * qd + 1] = c1[VW + 2 * qd] = c1[VW + 2 * qd + 1] = v1;
+            c2[2 * qd] = c2[2 * qd + 1] = c2[VW + 2 * qd] = c2[VW + 2 * qd + 1] = v2;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2 * VW; j++) {
+            c1[j] = LUT_ALL ? dequantize_lut(u.c1[j], lut, maxVal) : dequantize_color(u.c1[j], maxC);
+            c2[j] = LUT_ALL ? dequantize_lut(u.c2[j], lut, maxVal) : dequantize_color(u.c2[j], maxC);
+        }
+    }
+    float out[3][2][VW];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < VW; i++)
+            xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
+
+    float *p = a.dst + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        store_px<VW>(p + c * cs, out[c][0]);
+        store_px<VW>(p + c * cs + a.g.w, out[c][1]);
+    }
+}
+
 template <int CS, bool SUB, int VW, bool GL>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
     stage_tables<false>(smem, a.q, !GL, CS == CS_YCBCR);
     const float *s_lut = reinterpret_cast<const float *>(smem);
-    const float *lut = GL ? a.q.lut : s_lut;
     XformConst k;
     k.sc = a.sc;
     k.Lmax = a.q.Lmax;
@@ -378,78 +538,19 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
     const size_t cs = (size_t)a.g.w * a.g.h;
-    const float maxC = a.q.maxC;
-    const int maxVal = a.q.maxVal;
+    const int G = gridDim.x;
 
-    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
-        int f, bx, by;
-        tile_coords(t, a.g, f, bx, by);
-        const int ux = bx * 64 + tx, uy = by * NW + ty;
-        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
-            continue;
-
-        float c0[2 * VW], c1[2 * VW], c2[2 * VW];
-        {
-            const unsigned char *s = a.src[0] + (size_t)f * a.src_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
-                                     (size_t)ux * VW * a.bps;
-            int row[VW];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                load_samples<VW>(s + (size_t)r * a.stride[0], row, a.bps, a.aligned);
-#pragma unroll
-                for (int i = 0; i < VW; i++)
-                    c0[r * VW + i] = dequantize_lut(row[i], lut, maxVal);
-            }
+    DecUnit<SUB, VW> cur, nxt;
+    dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
+        dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
+        if (cur.valid) {
+            if constexpr (GL)
+                dec_process<CS, SUB, VW>(cur, a, k, a.q.lut, cs);
+            else
+                dec_process<CS, SUB, VW>(cur, a, k, s_lut, cs);
         }
-        if constexpr (SUB) {
-            constexpr int NQ = VW / 2;
-            int k1[NQ], k2[NQ];
-            load_samples<NQ>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)uy * a.stride[1] +
-                                 (size_t)ux * NQ * a.bps, k1, a.bps, a.aligned);
-            load_samples<NQ>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)uy * a.stride[2] +
-                                 (size_t)ux * NQ * a.bps, k2, a.bps, a.aligned);
-#pragma unroll
-            for (int qd = 0; qd < NQ; qd++) {
-                const float v1 = LUT_ALL ? dequantize_lut(k1[qd], lut, maxVal) : dequantize_color(k1[qd], maxC);
-                const float v2 = LUT_ALL ? dequantize_lut(k2[qd], lut, maxVal) : dequantize_color(k2[qd], maxC);
-                // src/luma_decoder.cpp:229-234: the sample is replicated to its 2x2 block
-                c1[2 * qd] = c1[2 * qd + 1] = c1[VW + 2 * qd] = c1[VW + 2 * qd + 1] = v1;
-                c2[2 * qd] = c2[2 * qd + 1] = c2[VW + 2 * qd] = c2[VW + 2 * qd + 1] = v2;
-            }
-        } else {
-#pragma unroll
-            for (int pl = 1; pl < 3; pl++) {
-                const unsigned char *s = a.src[pl] + (size_t)f * a.src_frame_stride[pl] +
-                                         (size_t)(2 * uy) * a.stride[pl] + (size_t)ux * VW * a.bps;
-                int row[VW];
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    load_samples<VW>(s + (size_t)r * a.stride[pl], row, a.bps, a.aligned);
-#pragma unroll
-                    for (int i = 0; i < VW; i++) {
-                        const float v = LUT_ALL ? dequantize_lut(row[i], lut, maxVal) : dequantize_color(row[i], maxC);
-                        if (pl == 1)
-                            c1[r * VW + i] = v;
-                        else
-                            c2[r * VW + i] = v;
-                    }
-                }
-            }
-        }
-
-        float out[3][2][VW];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int i = 0; i < VW; i++)
-                xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
-
-        float *p = a.dst + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * VW;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            store_px<VW>(p + c * cs, out[c][0]);
-            store_px<VW>(p + c * cs + a.g.w, out[c][1]);
-        }
+        cur = nxt;
     }
 }
 
@@ -526,7 +627,7 @@ __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
         if (!a.lut_channel)
             c[0] = quantize_color(v[0], a.q.maxC);
         else if (a.q.mode == 1)
-            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);
+            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);  // run-time step count
         else if (a.q.mode == 0)
             quantize_lut<0, 1>(v, c, s_lut, s_bucket, a.q);
         else

@@ -2,6 +2,7 @@
 // Host-side only logic here; the arithmetic is in luma_device.hpp / luma_kernels.hpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,7 +42,7 @@ struct lumahip_ctx {
     float *d_arr = nullptr;
     size_t d_arr_cap = 0;
 
-    int block_threads = 256;
+    int block_threads = 512;
     int blocks_per_cu = 0;  // 0 = occupancy query
 };
 
@@ -172,7 +173,7 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
 
     c->idx = build_lut_index(lut, (int)n);
     const LutIndex &ix = c->idx;
-    const size_t lut_floats = ((n + ix.pad) + 3) & ~(size_t)3;
+    const size_t lut_floats = ((n + std::max(ix.pad, 1)) + 3) & ~(size_t)3;
     std::vector<float> padded(lut_floats, __builtin_nanf(""));
     memcpy(padded.data(), lut, n * sizeof(float));
     (void)hipFree(c->d_lut);
@@ -244,22 +245,27 @@ typedef void (*enc_kernel_t)(const EncArgs);
 typedef void (*dec_kernel_t)(const DecArgs);
 
 template <int CS, bool SUB>
-static enc_kernel_t pick_enc2(int vw, int mode)
+static enc_kernel_t pick_enc2(int vw, int mode, int steps)
 {
-    if (mode == LUT_BUCKET_LDS)
+    if (mode == LUT_BUCKET_LDS) {
+        if (vw == 4 && steps == 1)
+            return k_encode<CS, SUB, 4, 11>;
+        if (vw == 4 && steps == 2)
+            return k_encode<CS, SUB, 4, 12>;
         return vw == 4 ? k_encode<CS, SUB, 4, 1> : k_encode<CS, SUB, 2, 1>;
+    }
     if (mode == LUT_LITERAL_LDS)
         return k_encode<CS, SUB, 2, 0>;
     return k_encode<CS, SUB, 2, 2>;
 }
 
-static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
+static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode, int steps)
 {
     switch (cs) {
-    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode) : pick_enc2<CS_LUV, false>(vw, mode);
-    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode) : pick_enc2<CS_RGB, false>(vw, mode);
-    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode) : pick_enc2<CS_YCBCR, false>(vw, mode);
-    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode) : pick_enc2<CS_XYZ, false>(vw, mode);
+    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode, steps) : pick_enc2<CS_LUV, false>(vw, mode, steps);
+    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode, steps) : pick_enc2<CS_RGB, false>(vw, mode, steps);
+    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode, steps) : pick_enc2<CS_YCBCR, false>(vw, mode, steps);
+    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode, steps) : pick_enc2<CS_XYZ, false>(vw, mode, steps);
     }
     return nullptr;
 }
@@ -378,7 +384,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
         if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
             a.aligned = 0;
     }
-    enc_kernel_t kern = pick_enc(c->q.cs, sub, vw, mode);
+    enc_kernel_t kern = pick_enc(c->q.cs, sub, vw, mode, c->q.steps);
     const size_t lds = lds_bytes(c, true);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

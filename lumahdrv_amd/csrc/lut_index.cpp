@@ -67,7 +67,7 @@ LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth)
             // bucket 0 also receives every value below it (key clamp), the last bucket every value above
             int s = (k == 0) ? 0 : p(from_bits((int64_t)(kmin + k) << shift));
             int e = (k == K - 1) ? maxVal - 1 : p(from_bits(((int64_t)(kmin + k + 1) << shift) - 1));
-            start[k] = (uint16_t)s;
+            start[k] = (uint16_t)(4 * s);  // byte offset into the table
             maxspan = std::max(maxspan, e - s);
         }
         int S = 0;
@@ -80,7 +80,7 @@ LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth)
             best.kmin = kmin;
             best.nbuckets = K;
             best.steps = S;
-            best.pad = 1 << S;
+            best.pad = (1 << S) + 1;
             best.start = std::move(start);
             have = true;
         }

@@ -33,8 +33,8 @@ struct LutIndex {
     int kmin = 0;       // key of bucket 0
     int nbuckets = 0;   // K
     int steps = 0;      // S
-    int pad = 0;        // NaN floats appended after the table so that probes up to l + 2^S - 1 stay in bounds
-    std::vector<uint16_t> start;  // K entries
+    int pad = 1;        // NaN floats appended after the table: probes reach index maxVal + 2^S
+    std::vector<uint16_t> start;  // K entries: BYTE offset (4 * first candidate index) per bucket
 };
 
 // lut has n = maxVal+1 entries

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3: N encode + N decode launches over 20 resident synthetic 4K frames
+(distinct batch per launch).  Prints nothing but a one-line summary; timing comes from the profiler."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import lumahdrv_amd as L  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    wl = sys.argv[2] if len(sys.argv) > 2 else "pq11_luv"
+    cfgs = {"pq11_luv": (L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, 1.0),
+            "pq10_ycbcr": (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01, 20.0),
+            "log12_luv": (L.PTF_LOG, 12, L.CS_LUV, 8, 1e4, 0.005, 1.0)}
+    ptf, bits, cs, bitsC, mx, mn, sc = cfgs[wl]
+    w, h, B = 3840, 2160, 20
+    n3 = 3 * w * h
+    dev = torch.device("cuda:0")
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(n * B * n3, dtype=torch.float32, device=dev)
+    out = torch.empty(n * B * n3, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(n * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_quantizer(ptf, bits, cs, bitsC, mx, mn, L.build_lut(ptf, bits, mx, mn))
+    ctx.synth_frames_device(src.data_ptr(), n3, n * B, w, h)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for b in range(n):
+            pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
+            ctx.encode_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, sc, 2, pl, st, psz)
+        for b in range(n):
+            pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
+            ctx.decode_frames_device(pl, st, psz, B, w, h, 2, sc, out.data_ptr() + b * B * n3 * 4, n3)
+    torch.cuda.synchronize()
+    print("prof_driver done: %d launches each of encode/decode, %d pixels per launch" % (2 * n, B * w * h))
+
+
+if __name__ == "__main__":
+    main()
