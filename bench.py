@@ -84,19 +84,16 @@ def main():
     w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
 
     # ---- quantizer: rank 0 builds the table on its host, RCCL-broadcasts it and the parameters over xGMI
-    params = torch.zeros(8, dtype=torch.float32, device=dev)
-    lut = torch.zeros(1 << bits, dtype=torch.float32, device=dev)
+    from lumahdrv_amd.sharding import broadcast_quantizer
+    cfg0 = lut0 = None
     if rank == 0:
-        lut.copy_(torch.from_numpy(L.build_lut(ptf, bits, maxLum, minLum)))
-        params.copy_(torch.tensor([ptf, bits, cs, bitsC, maxLum, minLum, sc, profile], dtype=torch.float32))
-    if world > 1:
-        dist.broadcast(lut, src=0)
-        dist.broadcast(params, src=0)
-    pv = params.cpu().tolist()
+        cfg0 = (ptf, bits, cs, bitsC, maxLum, minLum, sc, profile)
+        lut0 = L.build_lut(ptf, bits, maxLum, minLum)
+    cfg, lut = broadcast_quantizer(cfg0, lut0, dev)
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile = cfg
     ctx = L.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_quantizer(int(pv[0]), int(pv[1]), int(pv[2]), int(pv[3]), pv[4], pv[5], lut.cpu().numpy())
-    sc, profile = pv[6], int(pv[7])
+    ctx.set_quantizer(ptf, bits, cs, bitsC, maxLum, minLum, lut)
 
     # ---- resident synthetic stream: as many distinct batches as the step count needs (or memory allows)
     n3 = 3 * w * h

@@ -1,0 +1,85 @@
+// luma_decoder.h -- LumaDecoder with the reference's interface (include/luma/luma_decoder.h:60-175 there)
+// for the hot path: LumaDecoder(file) / initialize / run / decode / getBuffer / getParams / getQuantizer.
+//
+// decode() = run() (fetch the next frame's Y/U/V planes from the upstream stage) + ONE fused HIP kernel
+// (unpack + LUT / colour dequantize + 2x2 chroma replicate + inverse colour transform) into the decoder's
+// own LumaFrame, returned by pointer and valid until the next decode(), as in the reference.  Upstream is
+// a LumaPlaneSource (luma_planes.h); the reference's MKV demux + vpx_codec_decode attach there.
+#ifndef LUMA_HIP_DECODER_H
+#define LUMA_HIP_DECODER_H
+
+#include "luma_exception.h"
+#include "luma_frame.h"
+#include "luma_planes.h"
+#include "luma_quantizer.h"
+
+struct LumaDecoderParamsBase {
+    LumaDecoderParamsBase()
+        : ptf(LumaQuantizer::PTF_PSI), colorSpace(LumaQuantizer::CS_LUV), preScaling(1.0f), minLum(0.005f), maxLum(1e4f)
+    {
+    }
+    LumaQuantizer::ptf_t ptf;
+    LumaQuantizer::colorSpace_t colorSpace;
+    float preScaling, minLum, maxLum;
+};
+
+struct LumaDecoderParams : LumaDecoderParamsBase {
+    LumaDecoderParams() : ptfBitDepth(11), colorBitDepth(8), highBitDepth(true), stride(NULL), profile(2)
+    {
+        for (int i = 0; i < 3; i++)
+            width[i] = height[i] = 0;
+    }
+    unsigned int ptfBitDepth, colorBitDepth;
+    bool highBitDepth;
+    const int *stride;
+    int profile, width[3], height[3];
+};
+
+class LumaDecoderBase {
+public:
+    LumaDecoderBase() : m_initialized(false), m_input(NULL) {}
+    virtual ~LumaDecoderBase() {}
+    virtual bool initialize(const char *inputFile, bool verbose = 0) = 0;
+    virtual bool run() = 0;
+    virtual LumaFrame *decode() = 0;
+    LumaQuantizer *getQuantizer() { return &m_quant; }
+    LumaFrame *getFrame() { return &m_frame; }
+    bool initialized() { return m_initialized; }
+
+protected:
+    bool m_initialized;
+    const char *m_input;
+    LumaQuantizer m_quant;
+    LumaFrame m_frame;
+};
+
+class LumaDecoder : public LumaDecoderBase {
+public:
+    LumaDecoder(const char *inputFile = NULL, bool verbose = 0);
+    ~LumaDecoder();
+
+    // throws LumaException("Failed to locate Luma HDRv meta data in '<file>'") when the stream lacks the
+    // attachments 430..434, like the reference
+    bool initialize(const char *inputFile, bool verbose = 0);
+    bool run();
+    LumaFrame *decode();  // NULL at end of stream
+    void seekToTime(float tm, bool absolute = false);
+
+    unsigned char **getBuffer() { return m_planePtrs; }
+    LumaDecoderParams getParams() { return m_params; }
+    void setParams(LumaDecoderParams params) { m_params = params; }
+
+    // ---- additions ----
+    void setSource(LumaPlaneSource *src) { m_source = src; }  // not owned; default: raw plane stream
+
+private:
+    LumaDecoderParams m_params;
+    const LumaPlanes *m_vpxFrame;
+    unsigned char *m_planePtrs[3];
+    bool m_firstFrame;
+    LumaPlaneSource *m_source;
+    LumaRawStreamReader m_rawReader;
+    float m_time;
+};
+
+#endif

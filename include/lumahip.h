@@ -106,6 +106,14 @@ int lumahip_encode_frame_host(lumahip_ctx *ctx, const float *rgb, unsigned w, un
 int lumahip_decode_frame_host(lumahip_ctx *ctx, const unsigned char *const planes[3], const int stride[3],
                               unsigned w, unsigned h, int profile, float sc, float *rgb_out);
 
+/* Replaces LumaEncoder::setChannels(LumaFrame*) on its own (src/luma_encoder.cpp:196-201): quantize + pack a
+ * frame that is ALREADY colour-transformed.  And LumaDecoder::getVpxChannels on its own
+ * (src/luma_decoder.cpp:205-240): unpack + dequantize without the inverse colour transform. */
+int lumahip_pack_frame_host(lumahip_ctx *ctx, const float *transformed, unsigned w, unsigned h, int profile,
+                            unsigned char *const planes[3], const int stride[3], float *mean_lum);
+int lumahip_unpack_frame_host(lumahip_ctx *ctx, const unsigned char *const planes[3], const int stride[3],
+                              unsigned w, unsigned h, int profile, float *dequantized_out);
+
 /* Replaces LumaQuantizer::transformColorSpace(LumaFrame*, bool toCs, float sc)
  * (src/luma_quantizer.cpp:267-482): in place on a host frame.  Returns LUMAHIP_ERR_UNSUPPORTED where the
  * reference returns false. */

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
     "lumahip_set_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
-    "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_transform_color_space_host",
+    "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
     "lumahip_time_launches", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
@@ -86,6 +86,8 @@ def lib():
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
+    L.lumahip_pack_frame_host.argtypes = [vp, vp, u, u, i, pp3, ip3, C.POINTER(f)]
+    L.lumahip_unpack_frame_host.argtypes = [vp, pp3, ip3, u, u, i, vp]
     L.lumahip_transform_color_space_host.argtypes = [vp, vp, u, u, i, f]
     L.lumahip_quantize_array_host.argtypes = [vp, vp, vp, sz, u]
     L.lumahip_dequantize_array_host.argtypes = [vp, vp, vp, sz, u]
@@ -194,6 +196,26 @@ class Context:
         out = np.empty((3, h, w), dtype=np.float32)
         self._chk(self.L.lumahip_decode_frame_host(self.h, _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
                                                    _arr3(C.c_int, strides), w, h, profile, sc, out.ctypes.data))
+        return out
+
+    def pack_frame(self, transformed: np.ndarray, profile=2, align=32):
+        """LumaEncoder::setChannels on its own: quantize + pack an already colour-transformed frame"""
+        t = np.ascontiguousarray(transformed, dtype=np.float32)
+        _, h, w = t.shape
+        _, hs, st, _ = plane_geometry(w, h, profile, align)
+        planes = [np.zeros((hs[p], st[p]), dtype=np.uint8) for p in range(3)]
+        mean = C.c_float(0)
+        self._chk(self.L.lumahip_pack_frame_host(self.h, t.ctypes.data, w, h, profile,
+                                                 _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
+                                                 _arr3(C.c_int, st), C.byref(mean)))
+        return planes, st, float(mean.value)
+
+    def unpack_frame(self, planes, strides, w, h, profile=2) -> np.ndarray:
+        """LumaDecoder::getVpxChannels on its own: unpack + dequantize, no inverse colour transform"""
+        planes = [np.ascontiguousarray(p) for p in planes]
+        out = np.empty((3, h, w), dtype=np.float32)
+        self._chk(self.L.lumahip_unpack_frame_host(self.h, _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
+                                                   _arr3(C.c_int, strides), w, h, profile, out.ctypes.data))
         return out
 
     def transform_color_space(self, frame: np.ndarray, to_cs: bool, sc=1.0) -> np.ndarray:

@@ -1,0 +1,136 @@
+// Facade LumaDecoder: metadata handling as in the reference's initialize(), hot path through the C ABI.
+#include "../../../include/luma/luma_decoder.h"
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../../include/lumahip.h"
+
+LumaDecoder::LumaDecoder(const char *inputFile, bool verbose)
+    : m_vpxFrame(NULL), m_firstFrame(false), m_source(NULL), m_time(0.0f)
+{
+    m_planePtrs[0] = m_planePtrs[1] = m_planePtrs[2] = NULL;
+    if (inputFile != NULL) {
+        m_input = inputFile;
+        initialize(inputFile, verbose);
+    }
+}
+
+LumaDecoder::~LumaDecoder() {}
+
+bool LumaDecoder::initialize(const char *inputFile, bool verbose)
+{
+    if (inputFile == NULL)
+        return false;
+    m_input = inputFile;
+    if (!m_source)
+        m_source = &m_rawReader;
+    m_source->open(inputFile);
+    (void)verbose;
+
+    // collect the metadata attachments; 430..434 are mandatory, 435 / 436 keep their defaults when absent
+    unsigned char *buffer = NULL;
+    unsigned int id = 0, size = 0, mappingBytes = 0;
+    const float *mapping = NULL;
+    bool have430 = false, have431 = false, have432 = false, have433 = false;
+    for (unsigned int idx = 0; m_source->getAttachment(idx, &buffer, id, size); idx++) {
+        switch (id) {
+        case 430: memcpy(&m_params.ptfBitDepth, buffer, sizeof(unsigned int)); have430 = true; break;
+        case 431: memcpy(&m_params.colorBitDepth, buffer, sizeof(unsigned int)); have431 = true; break;
+        case 432: { int v; memcpy(&v, buffer, sizeof v); m_params.ptf = (LumaQuantizer::ptf_t)v; have432 = true; break; }
+        case 433: { int v; memcpy(&v, buffer, sizeof v); m_params.colorSpace = (LumaQuantizer::colorSpace_t)v; have433 = true; break; }
+        case 434: mapping = (const float *)buffer; mappingBytes = size; break;
+        case 435: memcpy(&m_params.preScaling, buffer, sizeof(float)); break;
+        case 436: memcpy(&m_params.maxLum, buffer, sizeof(float)); memcpy(&m_params.minLum, buffer + sizeof(float), sizeof(float)); break;
+        default: break;
+        }
+    }
+    if (!(have430 && have431 && have432 && have433 && mapping)) {
+        std::string msg = "Failed to locate Luma HDRv meta data in '" + std::string(inputFile) + "'";
+        throw LumaException(msg.c_str());
+    }
+
+    // Rebuild the table from the parameters, then lay the attachment's floats over its head: the attachment
+    // holds getSize() = maxVal entries, so the last entry always comes from this side's recomputation.
+    m_quant.setQuantizer(m_params.ptf, m_params.ptfBitDepth, m_params.colorSpace, m_params.colorBitDepth, m_params.maxLum,
+                         m_params.minLum);
+    const size_t tableBytes = ((size_t)m_quant.getSize() + 1) * sizeof(float);
+    memcpy(const_cast<float *>(m_quant.getMapping()), mapping, mappingBytes < tableBytes ? mappingBytes : tableBytes);
+    m_quant.syncMapping();
+
+    fprintf(stderr, "\nDecoding options:\n");
+    fprintf(stderr, "-------------------------------------------------------------------\n");
+    fprintf(stderr, "Transfer function (PTF):   %s\n", LumaQuantizer::name(m_params.ptf).c_str());
+    if (m_params.ptf == LumaQuantizer::PTF_PQ || m_params.ptf == LumaQuantizer::PTF_LOG || m_params.ptf == LumaQuantizer::PTF_LINEAR)
+        fprintf(stderr, "Encoding luminance range:  %.4f-%.2f\n", m_quant.getMinLum(), m_quant.getMaxLum());
+    fprintf(stderr, "Color space:               %s\n", LumaQuantizer::name(m_params.colorSpace).c_str());
+    fprintf(stderr, "PTF bit depth:             %d\n", m_params.ptfBitDepth);
+    fprintf(stderr, "Color bit depth:           %d\n", m_params.colorBitDepth);
+    fprintf(stderr, "Transform:                 HIP / gfx950 (lumahip ABI %d)\n", lumahip_abi_version());
+    fprintf(stderr, "-------------------------------------------------------------------\n\n");
+
+    // pre-fetch the first frame to learn the plane geometry (the reference pre-decodes frame 0 the same way)
+    m_firstFrame = false;
+    m_initialized = true;
+    if (!run()) {
+        m_initialized = false;
+        return false;
+    }
+    m_firstFrame = true;
+
+    m_params.highBitDepth = m_vpxFrame->highBitDepth;
+    m_params.stride = m_vpxFrame->stride;
+    m_params.profile = m_vpxFrame->profile();
+    for (int p = 0; p < 3; p++) {
+        m_params.width[p] = (int)m_vpxFrame->planeWidth(p);
+        m_params.height[p] = (int)m_vpxFrame->planeHeight(p);
+    }
+    return true;
+}
+
+bool LumaDecoder::run()
+{
+    if (!m_initialized) {
+        if (!initialize(m_input))
+            return false;
+    }
+    if (m_firstFrame) {  // frame 0 was fetched by initialize()
+        m_firstFrame = false;
+        return true;
+    }
+    m_vpxFrame = NULL;
+    if (!m_source->readFrame(&m_vpxFrame))  // probably end of stream
+        return false;
+    for (int p = 0; p < 3; p++)
+        m_planePtrs[p] = m_vpxFrame->planes[p];
+    return true;
+}
+
+LumaFrame *LumaDecoder::decode()
+{
+    if (!run())
+        return NULL;
+    if (!m_frame.width) {
+        m_frame.width = m_vpxFrame->d_w;
+        m_frame.height = m_vpxFrame->d_h;
+        m_frame.channels = 3;
+        m_frame.init();
+    }
+    const unsigned char *pl[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
+    const int rc = lumahip_decode_frame_host(m_quant.context(), pl, m_vpxFrame->stride, m_vpxFrame->d_w, m_vpxFrame->d_h,
+                                             m_vpxFrame->profile(), m_params.preScaling, m_frame.buffer);
+    if (rc != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_quant.context()));
+    return &m_frame;
+}
+
+void LumaDecoder::seekToTime(float tm, bool absolute)
+{
+    // the raw plane stream is constant-rate: time -> frame index at the stream's fps
+    m_time = absolute ? tm : m_time + tm;
+    if (m_time < 0.0f)
+        m_time = 0.0f;
+    const float fps = (m_source == &m_rawReader && m_rawReader.fps() > 0.0f) ? m_rawReader.fps() : 25.0f;
+    m_source->seekToFrame((unsigned int)(m_time * fps));
+    m_firstFrame = false;
+}

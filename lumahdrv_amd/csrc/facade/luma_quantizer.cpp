@@ -1,0 +1,149 @@
+// Facade LumaQuantizer: host bookkeeping + C-ABI calls.  The table is built by lumahip_build_lut (host libm,
+// as the reference does) and uploaded with lumahip_set_quantizer; transformColorSpace runs on the GPU.
+#include "../../../include/luma/luma_quantizer.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "../../../include/luma/luma_exception.h"
+#include "../../../include/lumahip.h"
+
+LumaQuantizer::LumaQuantizer()
+    : m_ctx(NULL), m_ptf(PTF_PSI), m_colorSpace(CS_LUV), m_Lmax(10000.0f), m_Lmin(0.005f), m_maxVal(0),
+      m_maxValColor(0), m_bitdepth(0), m_bitdepthColor(0), m_configured(false)
+{
+}
+
+LumaQuantizer::~LumaQuantizer()
+{
+    if (m_ctx)
+        lumahip_destroy(m_ctx);
+}
+
+void LumaQuantizer::requireContext()
+{
+    if (m_ctx)
+        return;
+    const int rc = lumahip_create(&m_ctx, -1);
+    if (rc != LUMAHIP_OK)
+        throw LumaException("No usable HIP device for the Luma HDRv quantizer (there is no CPU fallback)");
+}
+
+std::string LumaQuantizer::name(ptf_t ptf)
+{
+    switch (ptf) {
+    case PTF_PQ: return "Perceptual quantizer (PQ, SMPTE ST 2084)";
+    case PTF_LOG: return "Logarithmic";
+    case PTF_JND_HDRVDP: return "JND HDR-VDP";
+    case PTF_PSI: return "Perceptual - Ferwerda's t.v.i.";
+    case PTF_LINEAR: return "Linear scaling";
+    }
+    return "Undefined";
+}
+
+std::string LumaQuantizer::name(colorSpace_t cs)
+{
+    switch (cs) {
+    case CS_LUV: return "Lu'v'";
+    case CS_RGB: return "RGB";
+    case CS_YCBCR: return "YCbCr (ITU-R BT.2020)";
+    case CS_XYZ: return "XYZ";
+    }
+    return "Undefined";
+}
+
+void LumaQuantizer::setQuantizer(ptf_t ptf, unsigned int bitdepth, colorSpace_t cs, unsigned int bitdepthC, float maxLum,
+                                 float minLum)
+{
+    requireContext();
+    if (bitdepth < 1 || bitdepth > 16 || bitdepthC < 1 || bitdepthC > 16)
+        throw LumaException("PTF / colour bit depth must be in 1..16");
+    m_ptf = ptf;
+    m_bitdepth = bitdepth;
+    m_maxVal = (1u << bitdepth) - 1;
+    m_colorSpace = cs;
+    m_bitdepthColor = bitdepthC;
+    m_maxValColor = (1u << bitdepthC) - 1;
+    m_Lmax = maxLum;
+    m_Lmin = minLum;
+    m_mapping.assign((size_t)m_maxVal + 1, 0.0f);
+    const int rc = lumahip_build_lut((int)ptf, bitdepth, maxLum, minLum, m_mapping.data(), m_mapping.size());
+    if (rc == LUMAHIP_ERR_UNSUPPORTED)
+        throw LumaException("PSI / JND-HDR-VDP tables exist for at most 12 bits");
+    if (rc != LUMAHIP_OK)
+        throw LumaException("Cannot build the transfer function table (missing lumahdrv_amd/data/ptf_*.f32?)");
+    m_configured = true;
+    syncMapping();
+}
+
+void LumaQuantizer::syncMapping()
+{
+    if (!m_configured)
+        return;
+    const int rc = lumahip_set_quantizer(m_ctx, (int)m_ptf, m_bitdepth, (int)m_colorSpace, m_bitdepthColor, m_Lmax, m_Lmin,
+                                         m_mapping.data(), m_mapping.size());
+    if (rc != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_ctx));
+}
+
+// Scalar convenience API (the reference's per-sample entry points); same decisions as the reference:
+// bisection + nearest-of-two on the table, floor(maxC*v + 0.5) clamped for colour channels.
+float LumaQuantizer::quantize(const float val, const unsigned int ch) const
+{
+    if (ch == 0 || m_colorSpace == CS_RGB || m_colorSpace == CS_XYZ) {
+        int lo = 0, hi = (int)m_maxVal;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (val < m_mapping[mid])
+                hi = mid;
+            else
+                lo = mid;
+        }
+        return (val - m_mapping[lo] < m_mapping[hi] - val) ? (float)lo : (float)hi;
+    }
+    const float top = (float)m_maxValColor;
+    float r = std::floor(top * val + 0.5f);
+    r = std::min(top, r);
+    return std::max(0.0f, r);
+}
+
+float LumaQuantizer::dequantize(const float val, const unsigned int ch) const
+{
+    if (ch == 0 || m_colorSpace == CS_RGB || m_colorSpace == CS_XYZ) {
+        if (val < 0)
+            return m_mapping[0];
+        if (val >= m_maxVal)
+            return m_mapping[m_maxVal];
+        return m_mapping[(int)val];
+    }
+    return std::max(val / m_maxValColor, 1e-10f);
+}
+
+bool LumaQuantizer::transformColorSpace(LumaFrame *frame, bool toCs, float sc)
+{
+    if (!frame || !frame->buffer)
+        return false;
+    if (!m_configured) {
+        // a default-constructed reference quantizer is CS_LUV with no table; the transform needs none
+        requireContext();
+        m_ptf = PTF_LINEAR;
+        m_bitdepth = 1;
+        m_bitdepthColor = 8;
+        m_maxVal = 1;
+        m_maxValColor = 255;
+        m_mapping.assign(2, 0.0f);
+        m_mapping[1] = m_Lmax;
+        m_configured = true;
+        syncMapping();
+    }
+    const int rc = lumahip_transform_color_space_host(m_ctx, frame->buffer, frame->width, frame->height, toCs ? 1 : 0, sc);
+    if (rc == LUMAHIP_ERR_UNSUPPORTED) {
+        fprintf(stderr, toCs ? "Error! Unrecognized color transformation XYZ --> ?\n"
+                             : "Error! Unrecognized color transformation ? --> RGB\n");
+        return false;
+    }
+    if (rc != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_ctx));
+    return true;
+}

@@ -18,7 +18,10 @@
 
 namespace lh {
 
-enum : int { CS_LUV = 0, CS_RGB = 1, CS_YCBCR = 2, CS_XYZ = 3 };
+// 0..3 are the reference's colorSpace_t values; CS_PACK is internal: "frame is already colour-transformed"
+// (LumaEncoder::setChannels / LumaDecoder::getVpxChannels on their own), identity transform, channel 0
+// through the LUT and channels 1,2 through the colour quantizer.
+enum : int { CS_LUV = 0, CS_RGB = 1, CS_YCBCR = 2, CS_XYZ = 3, CS_PACK = 4 };
 
 #define LH_DEV static __device__ __forceinline__
 #define LH_DEVS __device__ __forceinline__  // explicit specialisations take no storage class
@@ -159,6 +162,14 @@ LH_DEVS void xform_fwd<CS_RGB>(float r, float g, float b, const XformConst &k, f
     c2 = b * k.sc;
 }
 
+template <>
+LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, float &c0, float &c1, float &c2)
+{
+    c0 = r;
+    c1 = g;
+    c2 = b;
+}
+
 // RGB -> Y'CbCr (BT.2020, PQ): src/luma_quantizer.cpp:317-354
 template <>
 LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
@@ -174,6 +185,14 @@ LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k,
 
 template <int CS>
 LH_DEV void xform_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b);
+
+template <>
+LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &, float &r, float &g, float &b)
+{
+    r = c0;
+    g = c1;
+    b = c2;
+}
 
 // Y'CbCr -> RGB: src/luma_quantizer.cpp:436-473
 template <>

@@ -42,6 +42,7 @@ struct lumahip_ctx {
     float *d_arr = nullptr;
     size_t d_arr_cap = 0;
 
+    int cs_override = -1;  // CS_PACK / CS_RGB while a pack-only / unpack-only call is in flight
     int block_threads = 512;
     int blocks_per_cu = 0;  // 0 = occupancy query
 };
@@ -220,7 +221,8 @@ static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket, bool force_globa
         if (need_bucket && q.mode == LUT_BUCKET_LDS)
             b += ((size_t)q.nbuckets * 2 + 15) & ~(size_t)15;
     }
-    if (q.cs == CS_YCBCR)
+    const int cs_eff = c->cs_override >= 0 ? c->cs_override : q.cs;
+    if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTables);
     return b;
 }
@@ -266,6 +268,7 @@ static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode, int steps)
     case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode, steps) : pick_enc2<CS_RGB, false>(vw, mode, steps);
     case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode, steps) : pick_enc2<CS_YCBCR, false>(vw, mode, steps);
     case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode, steps) : pick_enc2<CS_XYZ, false>(vw, mode, steps);
+    case CS_PACK: return sub ? pick_enc2<CS_PACK, true>(vw, mode, steps) : pick_enc2<CS_PACK, false>(vw, mode, steps);
     }
     return nullptr;
 }
@@ -285,6 +288,7 @@ static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl)
     case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl) : pick_dec2<CS_RGB, false>(vw, gl);
     case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl) : pick_dec2<CS_YCBCR, false>(vw, gl);
     case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl) : pick_dec2<CS_XYZ, false>(vw, gl);
+    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl) : pick_dec2<CS_PACK, false>(vw, gl);
     }
     return nullptr;
 }
@@ -297,7 +301,7 @@ static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile)
         return fail(c, LUMAHIP_ERR_ARG, "Invalid frame size %ux%u (must be even, non-zero)", w, h);
     if (profile < 0 || profile > 3)
         return fail(c, LUMAHIP_ERR_ARG, "profile must be 0..3 (got %d)", profile);
-    if (c->q.cs < 0 || c->q.cs > 3)
+    if (c->cs_override < 0 && (c->q.cs < 0 || c->q.cs > 3))
         return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", c->q.cs);
     return LUMAHIP_OK;
 }
@@ -384,7 +388,9 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
         if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
             a.aligned = 0;
     }
-    enc_kernel_t kern = pick_enc(c->q.cs, sub, vw, mode, c->q.steps);
+    const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
+    a.q.cs = cs_eff;
+    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode, c->q.steps);
     const size_t lds = lds_bytes(c, true);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -431,7 +437,9 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
         if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
             a.aligned = 0;
     }
-    dec_kernel_t kern = pick_dec(c->q.cs, sub, vw, gl);
+    const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
+    a.q.cs = cs_eff;
+    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl);
     const size_t lds = lds_bytes(c, false);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -740,6 +748,38 @@ extern "C" int lumahip_quantize_array_host(lumahip_ctx *c, const float *in, floa
 extern "C" int lumahip_dequantize_array_host(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch)
 {
     return array_op(c, in, out, n, ch, false);
+}
+
+// LumaEncoder::setChannels / LumaDecoder::getVpxChannels on their own: no colour transform.  Channel 0
+// goes through the LUT; channels 1,2 through the LUT for RGB / XYZ (src/luma_quantizer.cpp:219,251) --
+// which is the CS_RGB kernel with sc = 1 (x*1.0f and x/1.0f are exact) -- and through the colour quantizer
+// otherwise (CS_PACK).
+static int pack_cs(const lumahip_ctx *c) { return (c->q.cs == CS_RGB || c->q.cs == CS_XYZ) ? CS_RGB : CS_PACK; }
+
+extern "C" int lumahip_pack_frame_host(lumahip_ctx *c, const float *transformed, unsigned w, unsigned h, int profile,
+                                       unsigned char *const planes[3], const int stride[3], float *mean_lum)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    c->cs_override = pack_cs(c);
+    const int rc = lumahip_encode_frame_host(c, transformed, w, h, 1.0f, profile, planes, stride, mean_lum, nullptr);
+    c->cs_override = -1;
+    return rc;
+}
+
+extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                         unsigned w, unsigned h, int profile, float *dequantized_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    c->cs_override = pack_cs(c);
+    const int rc = lumahip_decode_frame_host(c, planes, stride, w, h, profile, 1.0f, dequantized_out);
+    c->cs_override = -1;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------- memory helpers
