@@ -90,8 +90,11 @@ LH_DEV float div_255_pos(float a)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Colour transforms, one pixel.  in: r,g,b (already multiplied by nothing); out: the three channel
-// values the reference stores back into the frame.
+// Colour transforms, one pixel.
+//   xform_fwd: in = r*sc, g*sc, b*sc (the caller applies the reference's `*sc` -- and skips it when
+//              sc == 1.0f, x*1.0f being exact); out = the three channel values the reference stores back.
+//   xform_inv: out = the reference's values BEFORE its final `/sc` (the caller divides -- and skips the
+//              division when sc == 1.0f, x/1.0f being exact).
 // ---------------------------------------------------------------------------------------------------
 
 struct XformConst {
@@ -130,7 +133,7 @@ LH_DEV void rgb_to_xyz(float R, float G, float B, float &X, float &Y, float &Z)
 template <>
 LH_DEVS void xform_fwd<CS_XYZ>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    rgb_to_xyz(r * k.sc, g * k.sc, b * k.sc, c0, c1, c2);
+    rgb_to_xyz(r, g, b, c0, c1, c2);
 }
 
 // RGB -> Lu'v': src/luma_quantizer.cpp:291-316
@@ -138,7 +141,7 @@ template <>
 LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
     float X, Y, Z;
-    rgb_to_xyz(r * k.sc, g * k.sc, b * k.sc, X, Y, Z);
+    rgb_to_xyz(r, g, b, X, Y, Z);
     const float sum = (X + Y) + Z;
     // X,Y,Z in [1e-4,1e8] (or NaN) after the clamp, sum in [3e-4,3e8]: div_nr is exact here
     const float rs = rcp_nr(sum);
@@ -157,9 +160,9 @@ template <>
 LH_DEVS void xform_fwd<CS_RGB>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
     // src/luma_quantizer.cpp:355-367
-    c0 = r * k.sc;
-    c1 = g * k.sc;
-    c2 = b * k.sc;
+    c0 = r;
+    c1 = g;
+    c2 = b;
 }
 
 template <>
@@ -174,9 +177,9 @@ LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, f
 template <>
 LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    const float R = pq_encode(std_max(r * k.sc, 1e-10f), k);
-    const float G = pq_encode(std_max(g * k.sc, 1e-10f), k);
-    const float B = pq_encode(std_max(b * k.sc, 1e-10f), k);
+    const float R = pq_encode(std_max(r, 1e-10f), k);
+    const float G = pq_encode(std_max(g, 1e-10f), k);
+    const float B = pq_encode(std_max(b, 1e-10f), k);
     const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
     c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
     c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
@@ -206,48 +209,84 @@ LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst 
     red = std_max(0.0f, std_min(1.0f, red));
     green = std_max(0.0f, std_min(1.0f, green));
     blue = std_max(0.0f, std_min(1.0f, blue));
-    r = div_ieee(pq_decode(red, k), k.sc);
-    g = div_ieee(pq_decode(green, k), k.sc);
-    b = div_ieee(pq_decode(blue, k), k.sc);
+    r = pq_decode(red, k);
+    g = pq_decode(green, k);
+    b = pq_decode(blue, k);
 }
 
-// XYZ -> RGB / sc: src/luma_quantizer.cpp:378-395 (matrix include/luma/luma_quantizer.h:84-87)
-LH_DEV void xyz_to_rgb_sc(float X, float Y, float Z, float sc, float &r, float &g, float &b)
+// XYZ -> RGB (before the final /sc): src/luma_quantizer.cpp:378-395 (matrix include/luma/luma_quantizer.h:84-87)
+LH_DEV void xyz_to_rgb(float X, float Y, float Z, float &r, float &g, float &b)
 {
-    r = div_ieee((3.240708f * X + -1.537259f * Y) + -0.498570f * Z, sc);
-    g = div_ieee((-0.969257f * X + 1.875995f * Y) + 0.041555f * Z, sc);
-    b = div_ieee((0.055636f * X + -0.203996f * Y) + 1.057069f * Z, sc);
+    r = (3.240708f * X + -1.537259f * Y) + -0.498570f * Z;
+    g = (-0.969257f * X + 1.875995f * Y) + 0.041555f * Z;
+    b = (0.055636f * X + -0.203996f * Y) + 1.057069f * Z;
 }
 
 template <>
 LH_DEVS void xform_inv<CS_XYZ>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
 {
-    xyz_to_rgb_sc(c0, c1, c2, k.sc, r, g, b);
+    xyz_to_rgb(c0, c1, c2, r, g, b);
 }
 
-// Lu'v' -> RGB: src/luma_quantizer.cpp:396-421
+// Lu'v' -> RGB: src/luma_quantizer.cpp:396-421.  The chroma-only part (everything that does not involve L)
+// is split out so that a 4:2:0 decoder evaluates it once per 2x2 quad:
+//   u = c1*255/410, v = c2*255/410, d = 6u - 16v + 12, x = 9u/d, y = 4v/d,  xy = x/y,  zy = (1-x-y)/y.
+// SAFE = both colour codes are <= maxC, so c1,c2 in [1e-10,1], u,v in [6e-11,0.63], d in [2.05,15.8],
+// x in [3e-11,2.8], y in [1.6e-11,1.3], |1-x-y| either 0 or >= ~1e-15: every operand and quotient is far
+// from the fp32 exponent limits and div_nr is bit-identical to IEEE division (see div_nr).  Otherwise
+// (out-of-range codes from a lossy upstream decoder: d may be <= 0, quotients may overflow) plain IEEE '/'.
+struct LuvChroma {
+    float xy, zy;
+};
+
+template <bool SAFE>
+LH_DEV LuvChroma luv_chroma(float c1, float c2)
+{
+    LuvChroma o;
+    if constexpr (SAFE) {
+        const float r410 = rcp_nr(410.0f);
+        const float u = div_nr_r(c1 * 255.0f, 410.0f, r410);
+        const float v = div_nr_r(c2 * 255.0f, 410.0f, r410);
+        const float d = ((6.0f * u) - 16.0f * v) + 12.0f;
+        const float rd = rcp_nr(d);
+        const float x = div_nr_r(9.0f * u, d, rd);
+        const float y = div_nr_r(4.0f * v, d, rd);
+        const float ry = rcp_nr(y);
+        o.xy = div_nr_r(x, y, ry);
+        o.zy = div_nr_r((1.0f - x) - y, y, ry);
+    } else {
+        const float u = div_ieee(c1 * 255.0f, 410.0f);
+        const float v = div_ieee(c2 * 255.0f, 410.0f);
+        const float d = ((6.0f * u) - 16.0f * v) + 12.0f;
+        const float x = div_ieee(9.0f * u, d);
+        const float y = div_ieee(4.0f * v, d);
+        o.xy = div_ieee(x, y);
+        o.zy = div_ieee((1.0f - x) - y, y);
+    }
+    return o;
+}
+
+LH_DEV void luv_apply(float L, const LuvChroma &q, float &r, float &g, float &b)
+{
+    const float Y = clamp_xyz(L);
+    const float X = clamp_xyz(q.xy * L);
+    const float Z = clamp_xyz(q.zy * L);
+    xyz_to_rgb(X, Y, Z, r, g, b);
+}
+
 template <>
 LH_DEVS void xform_inv<CS_LUV>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
 {
-    const float L = c0;
-    const float u = div_ieee(c1 * 255.0f, 410.0f);
-    const float v = div_ieee(c2 * 255.0f, 410.0f);
-    const float d = ((6.0f * u) - 16.0f * v) + 12.0f;
-    const float x = div_ieee(9.0f * u, d);
-    const float y = div_ieee(4.0f * v, d);
-    const float Y = clamp_xyz(L);
-    const float X = clamp_xyz(div_ieee(x, y) * L);
-    const float Z = clamp_xyz(div_ieee((1.0f - x) - y, y) * L);
-    xyz_to_rgb_sc(X, Y, Z, k.sc, r, g, b);
+    luv_apply(c0, luv_chroma<false>(c1, c2), r, g, b);
 }
 
 template <>
 LH_DEVS void xform_inv<CS_RGB>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
 {
     // src/luma_quantizer.cpp:422-435
-    r = div_ieee(c0, k.sc);
-    g = div_ieee(c1, k.sc);
-    b = div_ieee(c2, k.sc);
+    r = c0;
+    g = c1;
+    b = c2;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -278,6 +317,11 @@ LH_DEV int quantize_color(float val, float maxC)
 
 // colour-channel dequantizer: std::max(val/maxC, 1e-10f), src/luma_quantizer.cpp:261
 LH_DEV float dequantize_color(int code, float maxC) { return std_max(div_ieee((float)code, maxC), 1e-10f); }
+// code <= maxC (both < 2^16, maxC >= 1): operands and quotient in [0, 65535] -> div_nr is exact
+LH_DEV float dequantize_color_safe(int code, float maxC, float rmaxC)
+{
+    return std_max(div_nr_r((float)code, maxC, rmaxC), 1e-10f);
+}
 
 // LUT-channel dequantizer, src/luma_quantizer.cpp:253-258 (code is an unsigned sample, so val<0 never holds)
 template <typename LutPtr>

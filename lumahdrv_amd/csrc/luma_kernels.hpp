@@ -227,9 +227,9 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
 // LM: LUT search mode (0 literal/LDS, 2 literal/global, 1 bucketed run-time steps, 11/12 bucketed 1/2 steps).
 //
-// Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued before the current
-// unit is processed, so every wave keeps 6 KiB of HBM reads in flight while it computes (without this the
-// kernel sat at ~45 % SQ_WAIT_ANY, profiles/r01_pmc_summary.md).
+// Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued while the current
+// unit is still being searched / packed / stored (without this the kernel sat at ~45 % SQ_WAIT_ANY,
+// profiles/r01_early_pmc_summary.txt).
 
 template <int VW>
 struct EncUnit {
@@ -279,15 +279,20 @@ LH_DEV void stats_flush(EncStats &st, float *stats, int tx)
     st.mx = -__builtin_inff();
 }
 
-template <int CS, bool SUB, int VW, int LM, typename LutPtr>
-LH_DEV void enc_process(const EncUnit<VW> &u, const EncArgs &a, const XformConst &k, LutPtr lut,
-                        const uint16_t *s_bucket, EncStats &st)
+// colour transform of one unit (row-major pixel order inside the unit: j = r*VW + i)
+template <int CS, int VW>
+LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k, float (&c0)[2 * VW],
+                          float (&c1)[2 * VW], float (&c2)[2 * VW], EncStats &st)
 {
-    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
-    const float maxC = a.q.maxC;
-    const int f = u.f, ux = u.ux, uy = u.uy;
-    // colour transform (row-major pixel order inside the unit: j = r*VW + i)
-    float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+    if (k.sc != 1.0f) {  // wave-uniform; x*1.0f == x, so the multiply is skipped for the default preScaling
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    u.in[c][r][i] *= k.sc;
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -302,7 +307,15 @@ LH_DEV void enc_process(const EncUnit<VW> &u, const EncArgs &a, const XformConst
             st.mx = fmaxf(st.mx, c0[j]);
         }
     }
+}
 
+// quantize + subsample + pack + store one transformed unit
+template <int CS, bool SUB, int VW, int LM, typename LutPtr>
+LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const float (&c1)[2 * VW],
+                     const float (&c2)[2 * VW], const EncArgs &a, LutPtr lut, const uint16_t *s_bucket)
+{
+    constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
+    const float maxC = a.q.maxC;
     // plane 0
     int code0[2 * VW];
     quantize_lut<LM, 2 * VW>(c0, code0, lut, s_bucket, a.q);
@@ -401,10 +414,12 @@ __global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
     st.mn = __builtin_inff();
     st.mx = -__builtin_inff();
 
-    EncUnit<VW> cur, nxt;
-    enc_load<VW>(cur, a, blockIdx.x, tx, ty, NW, cs);
+    // Software pipeline: transform the current unit, THEN issue the next unit's loads (the current inputs are
+    // dead by then, so both units share one set of registers), then search / pack / store the current unit
+    // while the next unit's 6 KiB per wave are in flight.
+    EncUnit<VW> u;
+    enc_load<VW>(u, a, blockIdx.x, tx, ty, NW, cs);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
-        enc_load<VW>(nxt, a, t + G, tx, ty, NW, cs);  // prefetch: in flight while `cur` is processed
         if (a.stats) {
             const int f = t / a.g.tilesPerFrame;  // wave-uniform
             if (f != st.frame) {
@@ -412,13 +427,18 @@ __global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
                 st.frame = f;
             }
         }
-        if (cur.valid) {
+        const bool valid = u.valid;
+        const int f = u.f, ux = u.ux, uy = u.uy;
+        float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+        if (valid)
+            enc_transform<CS, VW>(u, a, k, c0, c1, c2, st);
+        enc_load<VW>(u, a, t + G, tx, ty, NW, cs);
+        if (valid) {
             if constexpr (LUT_LDS)
-                enc_process<CS, SUB, VW, LM>(cur, a, k, s_lut, s_bucket, st);
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_bucket);
             else
-                enc_process<CS, SUB, VW, LM>(cur, a, k, a.q.lut, s_bucket, st);
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_bucket);
         }
-        cur = nxt;
     }
     if (a.stats)
         stats_flush(st, a.stats, tx);
@@ -510,11 +530,41 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
         }
     }
     float out[3][2][VW];
+    if constexpr (CS == CS_LUV) {
+        // chroma-only factors once per quad (4:2:0) / per pixel (4:4:4), on the short division path when the
+        // codes are in range (always, unless a lossy upstream decoder produced garbage)
+        constexpr int NC = SUB ? VW / 2 : 2 * VW;
+        const int maxCi = (int)maxC;
+        const float rmaxC = rcp_nr(maxC);
+        LuvChroma ch[NC];
 #pragma unroll
-    for (int r = 0; r < 2; r++)
+        for (int j = 0; j < NC; j++) {
+            if (u.c1[j] <= maxCi && u.c2[j] <= maxCi)
+                ch[j] = luv_chroma<true>(dequantize_color_safe(u.c1[j], maxC, rmaxC), dequantize_color_safe(u.c2[j], maxC, rmaxC));
+            else
+                ch[j] = luv_chroma<false>(dequantize_color(u.c1[j], maxC), dequantize_color(u.c2[j], maxC));
+        }
 #pragma unroll
-        for (int i = 0; i < VW; i++)
-            xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                luv_apply(c0[r * VW + i], ch[SUB ? i / 2 : r * VW + i], out[0][r][i], out[1][r][i], out[2][r][i]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
+    }
+    if (k.sc != 1.0f) {  // wave-uniform; x/1.0f == x, so the division is skipped for the default preScaling
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    out[c][r][i] = div_ieee(out[c][r][i], k.sc);
+    }
 
     float *p = a.dst + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
 #pragma unroll
@@ -594,10 +644,14 @@ __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
         load_px<2>(p + 2 * a.chan_stride, v2);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            if constexpr (FWD)
-                xform_fwd<CS>(v0[e], v1[e], v2[e], k, o0[e], o1[e], o2[e]);
-            else
+            if constexpr (FWD) {
+                xform_fwd<CS>(v0[e] * k.sc, v1[e] * k.sc, v2[e] * k.sc, k, o0[e], o1[e], o2[e]);
+            } else {
                 xform_inv<CS>(v0[e], v1[e], v2[e], k, o0[e], o1[e], o2[e]);
+                o0[e] = div_ieee(o0[e], k.sc);
+                o1[e] = div_ieee(o1[e], k.sc);
+                o2[e] = div_ieee(o2[e], k.sc);
+            }
         }
         store_px<2>(p, o0);
         store_px<2>(p + a.chan_stride, o1);
