@@ -58,9 +58,13 @@ def parse():
 
 WORKLOADS = {
     # name: (ptf, bits, cs, bitsC, maxLum, minLum, preScaling, profile, description)
-    "pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0, 2, "PQ 11-bit Lu'v' 8-bit chroma, profile 2 (4:2:0 16-bit)"),
-    "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0, 2, "HDR10 recipe: PQ 10-bit YCbCr BT.2020, max/min 1000/0.01"),
-    "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0, 2, "LOG 12-bit Lu'v'"),
+    "pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0, 2, "PQ 11-bit Lu'v' 8-bit chroma, profile 2 (4:2:0 16-bit)",
+                 "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,bucketed LUT 1 step>"),
+    "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0, 2, "HDR10 recipe: PQ 10-bit YCbCr BT.2020 10-bit chroma, max/min 1000/0.01, preScaling 20",
+                   "RGB->PQ->Y'CbCr (8 glibc-exact powf per pixel: fp64-VALU-bound, not HBM-bound)",
+                   "lh::k_encode<CS_YCBCR,4:2:0,VW=4,bucketed LUT>"),
+    "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0, 2, "LOG 12-bit Lu'v' 8-bit chroma, profile 2",
+                  "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,bucketed LUT 2 steps>"),
 }
 
 
@@ -80,7 +84,7 @@ def main():
 
     import lumahdrv_amd as L   # after torch: one HIP runtime in the process
 
-    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc = WORKLOADS[args.workload]
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[args.workload]
     w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
 
     # ---- quantizer: rank 0 builds the table on its host, RCCL-broadcasts it and the parameters over xGMI
@@ -159,8 +163,10 @@ def main():
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
         "ms_per_step": round(1e3 * t_enc / K, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d %s encode (RGB->XYZ->Lu'v', LUT quantize, 4:2:0 16-bit pack), %d frames/step, "
-                               "%d-frame resident stream per GPU" % (w, h, desc, B, nfr),
+        "config": {"workload": "%dx%d %s encode (%s, LUT quantize, 4:2:0 16-bit pack), %d frames/step, "
+                               "%d-frame resident stream per GPU" % (w, h, desc, xf_desc, B, nfr),
+                   "timed": "the quantize (encode) pass; decode and encode+decode round trip are timed separately "
+                            "and reported as decode_mpix_s / roundtrip_mpix_s",
                    "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
                    "parallelism": "frame-sharded x%d" % n_gpus, "distinct_input_GB_per_gpu": round(ring_bytes / 1e9, 2)},
         "decode_mpix_s": round(n_gpus * K * px_step / t_dec / 1e6, 1),
@@ -182,13 +188,13 @@ def main():
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
-            if tj.get("pixels_per_launch") == px_step:
+            if tj.get("pixels_per_launch") == px_step and tj.get("workload") == args.workload and (w, h) == (W4K, H4K):
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             pass
         res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel": "lh::k_encode<LUV,4:2:0,VW=4,bucketed-LUT>", "kernel_ms": round(avg_ms, 4),
+                           "kernel": kname, "kernel_ms": round(avg_ms, 4),
                            "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
                            "decode_achieved_GBs": round(BYTES_PER_PIXEL * K * px_step / t_dec / 1e9, 1)}
 
