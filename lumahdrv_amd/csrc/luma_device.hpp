@@ -310,8 +310,11 @@ struct QuantDev {
 LH_DEV int quantize_color(float val, float maxC)
 {
     float res = floorf(maxC * val + 0.5f);
-    res = std_min(maxC, res);  // (res < maxC) ? res : maxC   -> NaN becomes maxC
-    res = std_max(0.0f, res);
+    // std::min(maxC, res) = (res < maxC) ? res : maxC returns maxC when res is NaN -- exactly IEEE minNum
+    // (v_min_f32), because the non-NaN operand is the one std::min falls back to.  The result is then
+    // non-NaN, and std::max(0.0f, t) = maxNum(0, t) for every non-NaN t (a -0 converts to code 0 either way).
+    res = __builtin_fminf(res, maxC);
+    res = __builtin_fmaxf(res, 0.0f);
     return (int)res;
 }
 

@@ -43,3 +43,38 @@ def test_facade_roundtrip_matches_oracle(oracle_mod, tmp_path, cs, bits, profile
     assert got["decoded"].split()[0] == "%016x" % o.fnv1a64(dec)
     assert "3 frames decoded" in r.stdout and "size %d" % ((1 << bits) - 1) in r.stdout
     assert got["odd-size:"] == "Invalid frame size"             # src/luma_encoder.cpp:118-119
+
+
+@pytest.mark.gpu
+def test_simple_enc_dec_tools_end_to_end(oracle_mod, tmp_path):
+    """BASELINE configs[0] harness: test_simple_enc with no arguments (five 1280x720 test frames), then
+    test_simple_dec writing EXRs; the first decoded frame, read back through ExrInterface's half rounding,
+    must equal the oracle's decode of the oracle's planes narrowed to half."""
+    import struct
+    import lumahdrv_amd
+    lumahdrv_amd.build_library()
+    o = oracle_mod
+    bind = os.path.join(ROOT, "lumahdrv_amd", "bin")
+    stream = str(tmp_path / "output.lhs")
+    r = subprocess.run([os.path.join(bind, "test_simple_enc")], cwd=str(tmp_path), capture_output=True, text=True, check=True)
+    assert "Encoding finished. 5 frames encoded." in r.stdout and os.path.exists(stream)
+    r = subprocess.run([os.path.join(bind, "test_simple_dec"), stream, str(tmp_path / "dec_%03d.exr")], capture_output=True,
+                       text=True, check=True)
+    assert "Decoding finished. 5 frames decoded." in r.stdout
+    # stream payload = header + 5 x tight planes; compare the planes of frame 1 with the oracle (SURVEY digests)
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    f = o.test_frame(1280, 720)
+    planes, st, _ = orc.encode(f, 1.0, 2)
+    raw = open(stream, "rb").read()
+    fb = 1280 * 720 * 2 + 2 * 640 * 360 * 2
+    body = raw[len(raw) - 5 * fb:]
+    y = np.frombuffer(body[:1280 * 720 * 2], dtype=np.uint8)
+    assert o.survey_digest(y) == "e0ff09731298e8f6"
+    assert np.array_equal(y.reshape(720, 2560), o.packed_rows(planes[0], 2560))
+    from tests.test_exr import read_exr_py
+    ch, _ = read_exr_py(str(tmp_path / "dec_001.exr"))
+    dec = orc.decode(planes, st, 1280, 720, 1.0, 2)
+    with np.errstate(over="ignore"):
+        for i, n in enumerate("RGB"):
+            exp = dec[i].astype(np.float16).astype(np.float32)
+            assert np.array_equal(ch[n].view(np.uint32), exp.view(np.uint32)), n
