@@ -252,3 +252,33 @@ def test_full_size_4k_frame_and_properties(L, oracle_mod):
     y2 = planes2[0][:sizes[0]].cpu().numpy().view("<u2").astype(np.int32)
     assert np.mean(np.abs(y1 - y2) <= 1) > 0.999
     q.ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("name,w,h,sc", [("log12_luv8", 7680, 4320, 1.0), ("pq10_ycbcr10", 3840, 2160, 20.0)])
+def test_full_size_other_configs(L, oracle_mod, name, w, h, sc):
+    """BASELINE configs[2] (HDR10 recipe, 4K) and configs[3] (8K LOG-12) at full size: one frame bit-exact both
+    ways against the multi-threaded oracle."""
+    import torch
+    o = oracle_mod
+    cfg = CONFIGS[name]
+    q, orc = pair(L, o, cfg)
+    dev = torch.device("cuda:0")
+    n3 = 3 * w * h
+    src = torch.empty(n3, dtype=torch.float32, device=dev)
+    q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    q.ctx.synth_frames_device(src.data_ptr(), n3, 1, w, h, 20250929, 3)
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    sizes = [hs[p] * st[p] for p in range(3)]
+    planes = [torch.zeros(sizes[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    q.ctx.encode_frames_device(src.data_ptr(), n3, 1, w, h, sc, 2, [p.data_ptr() for p in planes], st, sizes)
+    out = torch.empty(n3, dtype=torch.float32, device=dev)
+    q.ctx.decode_frames_device([p.data_ptr() for p in planes], st, sizes, 1, w, h, 2, sc, out.data_ptr(), n3)
+    torch.cuda.synchronize()
+    host = src.cpu().numpy().reshape(3, h, w)
+    assert same_bits(host, o.synth_frame(w, h, 20250929, 3))
+    nthreads = min(64, os.cpu_count() or 8)
+    e, _, _ = orc.encode(host.copy(), sc, 2, threads=nthreads)
+    for p in range(3):
+        assert np.array_equal(planes[p].cpu().numpy().reshape(hs[p], st[p]), e[p]), (name, p)
+    assert same_bits(out.cpu().numpy().reshape(3, h, w), orc.decode(e, st, w, h, sc, 2, threads=nthreads)), name
+    q.ctx.set_stream(None)
