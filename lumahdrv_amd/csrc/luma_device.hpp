@@ -140,8 +140,18 @@ LH_DEVS void xform_fwd<CS_XYZ>(float r, float g, float b, const XformConst &k, f
 template <>
 LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    float X, Y, Z;
-    rgb_to_xyz(r, g, b, X, Y, Z);
+    // The three matrix rows have strictly positive coefficients whose first two sum to < 1, so the raw X, Y, Z
+    // are NaN together or not at all (a NaN input, or +inf and -inf inputs; overflow can only give +-inf).
+    // Non-NaN values take the 1-instruction clamp v_med3_f32(v, 1e-4, 1e8) == max(min(v,1e8),1e-4); in the
+    // NaN case the reference's std::min/max pass the NaN through, so the raw (NaN) values are selected back
+    // and NaN then propagates through the rest of the arithmetic exactly as it does in the reference.
+    const float Xr = (0.412424f * r + 0.357579f * g) + 0.180464f * b;
+    const float Yr = (0.212656f * r + 0.715158f * g) + 0.072186f * b;
+    const float Zr = (0.019332f * r + 0.119193f * g) + 0.950444f * b;
+    const bool any_nan = (Yr != Yr);
+    const float X = any_nan ? Xr : __builtin_amdgcn_fmed3f(Xr, 0.0001f, 100000000.0f);
+    const float Y = any_nan ? Yr : __builtin_amdgcn_fmed3f(Yr, 0.0001f, 100000000.0f);
+    const float Z = any_nan ? Zr : __builtin_amdgcn_fmed3f(Zr, 0.0001f, 100000000.0f);
     const float sum = (X + Y) + Z;
     // X,Y,Z in [1e-4,1e8] (or NaN) after the clamp, sum in [3e-4,3e8]: div_nr is exact here
     const float rs = rcp_nr(sum);
@@ -150,8 +160,8 @@ LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, f
     // x,y in (0,1], x+y<=1+ulp: den = 3 - 2x + 12y in [1,15]; numerators in [1e-12,9]
     const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
     const float rd = rcp_nr(den);
+    // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410: div_255_pos is exact
     c0 = Y;
-    // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410 (or NaN): div_255_pos is exact
     c1 = div_255_pos(div_nr_r(4.0f * x, den, rd) * 410.f);
     c2 = div_255_pos(div_nr_r(9.0f * y, den, rd) * 410.f);
 }

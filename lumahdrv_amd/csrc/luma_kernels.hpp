@@ -16,7 +16,16 @@
 
 #include "luma_device.hpp"
 
+
 namespace lh {
+
+// Minimum waves per SIMD the encode kernels are register-allocated for.  The light variants (Lu'v' / pack-only,
+// 4:2:0 or VW=2) fit 80 VGPRs without spilling and run 6 waves per SIMD; the heavy ones (fp64 powf, three LUT
+// searches per pixel, 4:4:4 with VW=4) would spill at that bound and keep the 4-wave / 128-VGPR budget.
+template <int CS, bool SUB, int VW>
+struct EncWaves {
+    static constexpr int value = ((CS == CS_LUV || CS == CS_PACK) && (SUB || VW == 2)) ? 6 : 4;
+};
 
 struct FrameGeom {
     int w, h;            // luma size (even)
@@ -316,18 +325,19 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
     const float maxC = a.q.maxC;
-    // plane 0
-    int code0[2 * VW];
-    quantize_lut<LM, 2 * VW>(c0, code0, lut, s_bucket, a.q);
+    // plane 0, one row (VW searches in flight) at a time: keeps the live register set small enough for
+    // 6 waves per SIMD
     {
         unsigned char *d = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] +
                            (size_t)ux * VW * a.bps;
-        int row[VW];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
+            float v[VW];
+            int row[VW];
 #pragma unroll
             for (int i = 0; i < VW; i++)
-                row[i] = code0[r * VW + i];
+                v[i] = c0[r * VW + i];
+            quantize_lut<LM, VW>(v, row, lut, s_bucket, a.q);
             store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
         }
     }
@@ -386,7 +396,7 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
 }
 
 template <int CS, bool SUB, int VW, int LM>
-__global__ __launch_bounds__(1024) void k_encode(const EncArgs a)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool LUT_LDS = (LM != 2);
