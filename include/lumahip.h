@@ -136,6 +136,16 @@ int lumahip_encode_frames_device(lumahip_ctx *ctx, const float *rgb_dev, size_t 
 int lumahip_decode_frames_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
                                  const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
                                  int profile, float sc, float *rgb_dev, size_t frame_stride);
+/* Decode fused with the display-side transform of the reference's player (the step on the far side of the decode
+ * path: src/lumaplay_dequantizer.frag:145-156 -- exposure, optional 8-bit LDR simulation, optional sigmoid tone
+ * curve n = sig = 0.8, display gamma) into RGBA8 (4 B/pixel, rows rgba_stride bytes apart, alpha 255).
+ * rgb_dev may be NULL when only the display image is wanted (3 B read + 4 B written per pixel).  The reference's
+ * shader is not bit-reproducible (GL_LINEAR-filtered LUT texture), so this output is specified to +-1 code. */
+int lumahip_decode_display_frames_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                         const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
+                                         int profile, float sc, float *rgb_dev_or_null, size_t frame_stride,
+                                         unsigned char *rgba_dev, int rgba_stride, size_t rgba_frame_stride,
+                                         float exposure, float gamma, int do_tmo, int ldr_sim);
 int lumahip_transform_color_space_device(lumahip_ctx *ctx, float *frames_dev, size_t frame_stride, unsigned nframes,
                                          unsigned w, unsigned h, int toCs, float sc);
 
@@ -151,6 +161,11 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
                           unsigned nframes, unsigned w, unsigned h, float sc, int profile,
                           unsigned char *const planes_dev[3], const int stride[3],
                           const size_t plane_frame_stride[3], float *avg_ms);
+
+/* Pin caller-owned host memory (hipHostRegister) so that the _host entry points DMA it at PCIe rate instead
+ * of going through the runtime's pageable staging path.  Optional; unregister before freeing the memory. */
+int lumahip_host_register(lumahip_ctx *ctx, void *host_ptr, size_t bytes);
+int lumahip_host_unregister(lumahip_ctx *ctx, void *host_ptr);
 
 /* ---- device memory helpers (for hosts without their own allocator, e.g. the C++ facade) -------- */
 int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);

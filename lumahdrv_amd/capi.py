@@ -22,8 +22,8 @@ SYMBOLS = [
     "lumahip_set_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_encode_frames_device",
-    "lumahip_decode_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
-    "lumahip_time_launches", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+    "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
+    "lumahip_time_launches", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
 
 
@@ -93,9 +93,12 @@ def lib():
     L.lumahip_dequantize_array_host.argtypes = [vp, vp, vp, sz, u]
     L.lumahip_encode_frames_device.argtypes = [vp, vp, sz, u, u, u, f, i, pp3, ip3, sp3, vp]
     L.lumahip_decode_frames_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, vp, sz]
+    L.lumahip_decode_display_frames_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, vp, sz, vp, i, sz, f, f, i, i]
     L.lumahip_transform_color_space_device.argtypes = [vp, vp, sz, u, u, u, i, f]
     L.lumahip_synth_frames_device.argtypes = [vp, vp, sz, u, u, u, C.c_uint64, C.c_uint64]
     L.lumahip_time_launches.argtypes = [vp, i, i, vp, sz, u, u, u, f, i, pp3, ip3, sp3, C.POINTER(f)]
+    L.lumahip_host_register.argtypes = [vp, vp, sz]
+    L.lumahip_host_unregister.argtypes = [vp, vp]
     L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
     L.lumahip_free.argtypes = [vp, vp]
     L.lumahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -249,6 +252,15 @@ class Context:
                                                       _arr3(C.c_size_t, plane_frame_strides), nframes, w, h, profile,
                                                       sc, rgb_ptr, frame_stride))
 
+    def decode_display_frames_device(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, profile, sc, rgba_ptr,
+                                     rgba_stride, rgba_frame_stride, exposure=1.0, gamma=2.2, do_tmo=False,
+                                     ldr_sim=False, rgb_ptr=None, frame_stride=0):
+        """decode fused with the player's display transform -> RGBA8"""
+        self._chk(self.L.lumahip_decode_display_frames_device(
+            self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides), _arr3(C.c_size_t, plane_frame_strides),
+            nframes, w, h, profile, sc, rgb_ptr, frame_stride, rgba_ptr, rgba_stride, rgba_frame_stride, exposure, gamma,
+            int(bool(do_tmo)), int(bool(ldr_sim))))
+
     def transform_frames_device(self, ptr, frame_stride, nframes, w, h, to_cs, sc):
         self._chk(self.L.lumahip_transform_color_space_device(self.h, ptr, frame_stride, nframes, w, h,
                                                               int(bool(to_cs)), sc))
@@ -264,6 +276,13 @@ class Context:
                                                profile, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
                                                _arr3(C.c_size_t, plane_frame_strides), C.byref(ms)))
         return float(ms.value)
+
+    def host_register(self, arr: np.ndarray):
+        """pin a numpy array's memory for PCIe-rate transfers by the host entry points"""
+        self._chk(self.L.lumahip_host_register(self.h, arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._chk(self.L.lumahip_host_unregister(self.h, arr.ctypes.data))
 
     # ---- raw device memory (hosts without torch)
     def malloc(self, nbytes) -> int:

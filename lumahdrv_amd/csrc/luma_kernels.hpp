@@ -55,11 +55,18 @@ struct DecArgs {
     const unsigned char *src[3];
     int stride[3];
     size_t src_frame_stride[3];
-    float *dst;
+    float *dst;           // nullable when only the display output is wanted
     size_t frame_stride;
     float sc;
     int bps;
     int aligned;
+    // optional display epilogue (lumaplay's fragment shader, src/lumaplay_dequantizer.frag:145-156):
+    // RGBA8, 4 bytes per pixel, rows disp_stride bytes apart
+    unsigned char *disp;
+    int disp_stride;
+    size_t disp_frame_stride;
+    float exposure, inv_gamma;
+    int do_tmo, ldr_sim;
 };
 
 constexpr int LDS_ALIGN = 16;
@@ -510,7 +517,7 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
-template <int CS, bool SUB, int VW, typename LutPtr>
+template <int CS, bool SUB, int VW, bool DISP, typename LutPtr>
 LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, size_t cs)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
@@ -576,15 +583,54 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
                     out[c][r][i] = div_ieee(out[c][r][i], k.sc);
     }
 
-    float *p = a.dst + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+    if (!DISP || a.dst) {
+        float *p = a.dst + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        store_px<VW>(p + c * cs, out[c][0]);
-        store_px<VW>(p + c * cs + a.g.w, out[c][1]);
+        for (int c = 0; c < 3; c++) {
+            store_px<VW>(p + c * cs, out[c][0]);
+            store_px<VW>(p + c * cs + a.g.w, out[c][1]);
+        }
+    }
+    if constexpr (DISP) {
+        // Display-side transform of the player (src/lumaplay_dequantizer.frag:145-156) on the decoded,
+        // already /sc-scaled RGB: exposure, optional 8-bit LDR simulation, optional sigmoid tone curve,
+        // display gamma, 8-bit UNORM.  Not bit-pinned by the reference (its LUT texture is GL_LINEAR filtered),
+        // so the fast fp32 pow (v_exp(v_log)) is used here; tolerance +-1 code against a float64 evaluation.
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            uint32_t px[VW];
+#pragma unroll
+            for (int i = 0; i < VW; i++) {
+                uint32_t packed = 0xff000000u;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float v = out[c][r][i];
+                    if (a.ldr_sim)
+                        v = a.exposure * fmaxf(1.0f, fminf(256.0f, floorf(256.0f * v))) * (1.0f / 256.0f);
+                    else
+                        v = v * a.exposure;
+                    if (a.do_tmo) {
+                        const float vn = __powf(fmaxf(v, 0.0f), 0.8f);
+                        v = vn / (vn + 0.83650957f);  // pow(0.8, 0.8)
+                    }
+                    v = __powf(fmaxf(v, 0.0f), a.inv_gamma);
+                    v = fminf(fmaxf(v, 0.0f), 1.0f);  // NaN -> 0
+                    packed |= (uint32_t)(v * 255.0f + 0.5f) << (8 * c);
+                }
+                px[i] = packed;
+            }
+            unsigned char *d = a.disp + (size_t)u.f * a.disp_frame_stride + (size_t)(2 * u.uy + r) * a.disp_stride +
+                               (size_t)u.ux * VW * 4;
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                reinterpret_cast<uint32_t *>(d)[i] = px[i];
+        }
     }
 }
 
-template <int CS, bool SUB, int VW, bool GL>
+// DISP: additionally (or only) emit the RGBA8 display image -- a separate instantiation so that the plain
+// decoder does not carry the epilogue's registers (it cost 8 % when it was a run-time branch)
+template <int CS, bool SUB, int VW, bool GL, bool DISP = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -606,9 +652,9 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         if (cur.valid) {
             if constexpr (GL)
-                dec_process<CS, SUB, VW>(cur, a, k, a.q.lut, cs);
+                dec_process<CS, SUB, VW, DISP>(cur, a, k, a.q.lut, cs);
             else
-                dec_process<CS, SUB, VW>(cur, a, k, s_lut, cs);
+                dec_process<CS, SUB, VW, DISP>(cur, a, k, s_lut, cs);
         }
         cur = nxt;
     }

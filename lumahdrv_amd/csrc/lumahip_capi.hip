@@ -274,21 +274,26 @@ static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode, int steps)
 }
 
 template <int CS, bool SUB>
-static dec_kernel_t pick_dec2(int vw, bool gl)
+static dec_kernel_t pick_dec2(int vw, bool gl, bool disp)
 {
+    if (disp) {
+        if (gl)
+            return k_decode<CS, SUB, 2, true, true>;
+        return vw == 4 ? k_decode<CS, SUB, 4, false, true> : k_decode<CS, SUB, 2, false, true>;
+    }
     if (gl)
         return k_decode<CS, SUB, 2, true>;
     return vw == 4 ? k_decode<CS, SUB, 4, false> : k_decode<CS, SUB, 2, false>;
 }
 
-static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl)
+static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp)
 {
     switch (cs) {
-    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl) : pick_dec2<CS_LUV, false>(vw, gl);
-    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl) : pick_dec2<CS_RGB, false>(vw, gl);
-    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl) : pick_dec2<CS_YCBCR, false>(vw, gl);
-    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl) : pick_dec2<CS_XYZ, false>(vw, gl);
-    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl) : pick_dec2<CS_PACK, false>(vw, gl);
+    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp) : pick_dec2<CS_LUV, false>(vw, gl, disp);
+    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp) : pick_dec2<CS_RGB, false>(vw, gl, disp);
+    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp) : pick_dec2<CS_YCBCR, false>(vw, gl, disp);
+    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp) : pick_dec2<CS_XYZ, false>(vw, gl, disp);
+    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp) : pick_dec2<CS_PACK, false>(vw, gl, disp);
     }
     return nullptr;
 }
@@ -398,11 +403,19 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     return LUMAHIP_OK;
 }
 
-extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
-                                            const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
-                                            float sc, float *rgb, size_t frame_stride)
+struct DisplayParams {
+    unsigned char *rgba = nullptr;
+    int stride = 0;
+    size_t frame_stride = 0;
+    float exposure = 1.0f, gamma = 2.2f;
+    int do_tmo = 0, ldr_sim = 0;
+};
+
+static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                       unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
+                       const DisplayParams &dp)
 {
-    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
+    if (!c || (!rgb && !dp.rgba) || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     int rc = check_geom(c, w, h, profile);
     if (rc)
@@ -414,6 +427,8 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
     int vw = (!gl && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    if (dp.rgba && (!is_aligned(dp.rgba, 4) || (dp.stride % 4) != 0 || (dp.frame_stride % 4) != 0 || dp.stride < (int)(4 * w)))
+        return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
     DecArgs a{};
     a.q = c->q;
     const int threads = c->block_threads;
@@ -423,6 +438,13 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
     a.sc = sc;
     a.bps = bps;
     a.aligned = 1;
+    a.disp = dp.rgba;
+    a.disp_stride = dp.stride;
+    a.disp_frame_stride = dp.frame_stride;
+    a.exposure = dp.exposure;
+    a.inv_gamma = 1.0f / dp.gamma;
+    a.do_tmo = dp.do_tmo;
+    a.ldr_sim = dp.ldr_sim;
     for (int p = 0; p < 3; p++) {
         if (!planes[p])
             return fail(c, LUMAHIP_ERR_ARG, "null plane %d", p);
@@ -435,7 +457,7 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
     }
     const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
-    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl);
+    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
     const size_t lds = lds_bytes(c, false);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -443,6 +465,35 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                            float sc, float *rgb, size_t frame_stride)
+{
+    if (!rgb)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb, frame_stride, DisplayParams());
+}
+
+extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsigned char *const planes[3],
+                                                    const int stride[3], const size_t pfs[3], unsigned nframes, unsigned w,
+                                                    unsigned h, int profile, float sc, float *rgb_or_null,
+                                                    size_t frame_stride, unsigned char *rgba, int rgba_stride,
+                                                    size_t rgba_frame_stride, float exposure, float gamma, int do_tmo,
+                                                    int ldr_sim)
+{
+    if (!rgba || !(gamma > 0.0f))
+        return fail(c, LUMAHIP_ERR_ARG, "display output needs a buffer and gamma > 0");
+    DisplayParams dp;
+    dp.rgba = rgba;
+    dp.stride = rgba_stride;
+    dp.frame_stride = rgba_frame_stride;
+    dp.exposure = exposure;
+    dp.gamma = gamma;
+    dp.do_tmo = do_tmo;
+    dp.ldr_sim = ldr_sim;
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_or_null, frame_stride, dp);
 }
 
 typedef void (*xf_kernel_t)(const XfArgs);
@@ -779,6 +830,24 @@ extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *co
 }
 
 // ---------------------------------------------------------------------------------------- memory helpers
+
+extern "C" int lumahip_host_register(lumahip_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_host_unregister(lumahip_ctx *c, void *p)
+{
+    if (!c || !p)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostUnregister(p));
+    return LUMAHIP_OK;
+}
 
 extern "C" int lumahip_malloc(lumahip_ctx *c, void **p, size_t bytes)
 {

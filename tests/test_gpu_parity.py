@@ -282,3 +282,39 @@ def test_full_size_other_configs(L, oracle_mod, name, w, h, sc):
         assert np.array_equal(planes[p].cpu().numpy().reshape(hs[p], st[p]), e[p]), (name, p)
     assert same_bits(out.cpu().numpy().reshape(3, h, w), orc.decode(e, st, w, h, sc, 2, threads=nthreads)), name
     q.ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("do_tmo,ldr_sim,exposure,gamma", [(0, 0, 1.0, 2.2), (1, 0, 0.02, 2.2), (0, 1, 1.0, 1.8), (1, 1, 4.0, 2.4)])
+def test_decode_display_transform(L, oracle_mod, do_tmo, ldr_sim, exposure, gamma):
+    """decode fused with the player's display transform (src/lumaplay_dequantizer.frag:145-156): RGBA8 within
+    +-1 code of a float64 evaluation on the (bit-exact) decoded floats; the float output, when also requested,
+    stays bit-exact."""
+    import torch
+    o = oracle_mod
+    w, h = 256, 64
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    f = o.synth_frame(w, h, frame=11) * np.float32(0.01)
+    planes, st, _ = orc.encode(f.copy(), 1.0, 2)
+    dec = orc.decode(planes, st, w, h, 1.0, 2).astype(np.float64)
+    dev = torch.device("cuda:0")
+    tp = [torch.from_numpy(p.copy()).to(dev) for p in planes]
+    rgba = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
+    rgb = torch.zeros(3 * h * w, dtype=torch.float32, device=dev)
+    q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    q.ctx.decode_display_frames_device([t.data_ptr() for t in tp], st, [0, 0, 0], 1, w, h, 2, 1.0, rgba.data_ptr(), 4 * w, 0,
+                                       exposure, gamma, do_tmo, ldr_sim, rgb_ptr=rgb.data_ptr(), frame_stride=3 * w * h)
+    torch.cuda.synchronize()
+    q.ctx.set_stream(None)
+    assert same_bits(rgb.cpu().numpy().reshape(3, h, w), dec.astype(np.float32))
+    v = dec
+    v = exposure * np.clip(np.floor(256.0 * v), 1, 256) / 256.0 if ldr_sim else v * exposure
+    if do_tmo:
+        vn = np.maximum(v, 0) ** 0.8
+        v = vn / (vn + 0.8 ** 0.8)
+    v = np.clip(np.maximum(v, 0) ** (1.0 / gamma), 0, 1)
+    exp = np.floor(v * 255.0 + 0.5).astype(np.int32)
+    got = rgba.cpu().numpy().reshape(h, w, 4).astype(np.int32)
+    assert np.all(got[..., 3] == 255)
+    for c in range(3):
+        assert np.max(np.abs(got[..., c] - exp[c])) <= 1, c
+    assert np.mean(got[..., :3] == np.moveaxis(exp, 0, -1)) > 0.98
