@@ -61,8 +61,10 @@ int lumahip_create(lumahip_ctx **out, int device);
 void lumahip_destroy(lumahip_ctx *ctx);
 const char *lumahip_last_error(const lumahip_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead of the context's own
- * stream; NULL restores the context's stream. */
+ * non-blocking stream.  NULL is a valid handle and means the device's default (null) stream -- which is what
+ * PyTorch's default stream is.  lumahip_reset_stream goes back to the context's own stream. */
 int lumahip_set_stream(lumahip_ctx *ctx, void *hip_stream);
+int lumahip_reset_stream(lumahip_ctx *ctx);
 int lumahip_sync(lumahip_ctx *ctx);
 
 /* ---- quantizer --------------------------------------------------------------------------------- */
@@ -148,6 +150,10 @@ int lumahip_decode_display_frames_device(lumahip_ctx *ctx, const unsigned char *
                                          float exposure, float gamma, int do_tmo, int ldr_sim);
 int lumahip_transform_color_space_device(lumahip_ctx *ctx, float *frames_dev, size_t frame_stride, unsigned nframes,
                                          unsigned w, unsigned h, int toCs, float sc);
+
+/* array quantize / dequantize on device-resident values (asynchronous on the context's stream) */
+int lumahip_quantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);
+int lumahip_dequantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);
 
 /* Synthetic benchmark input, generated on the device by the integer-only recipe of SURVEY.md 8(d)
  * (identical to the oracle's lo_synth_frame): frame index first_frame + f at dst_dev + f*frame_stride. */

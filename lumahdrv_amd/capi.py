@@ -19,9 +19,10 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
-    "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_encode_frames_device",
+    "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
+    "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
     "lumahip_time_launches", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
@@ -80,6 +81,7 @@ def lib():
     L.lumahip_last_error.argtypes = [vp]
     L.lumahip_last_error.restype = C.c_char_p
     L.lumahip_set_stream.argtypes = [vp, vp]
+    L.lumahip_reset_stream.argtypes = [vp]
     L.lumahip_sync.argtypes = [vp]
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
@@ -91,6 +93,8 @@ def lib():
     L.lumahip_transform_color_space_host.argtypes = [vp, vp, u, u, i, f]
     L.lumahip_quantize_array_host.argtypes = [vp, vp, vp, sz, u]
     L.lumahip_dequantize_array_host.argtypes = [vp, vp, vp, sz, u]
+    L.lumahip_quantize_array_device.argtypes = [vp, vp, vp, sz, u]
+    L.lumahip_dequantize_array_device.argtypes = [vp, vp, vp, sz, u]
     L.lumahip_encode_frames_device.argtypes = [vp, vp, sz, u, u, u, f, i, pp3, ip3, sp3, vp]
     L.lumahip_decode_frames_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, vp, sz]
     L.lumahip_decode_display_frames_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, vp, sz, vp, i, sz, f, f, i, i]
@@ -160,7 +164,12 @@ class Context:
 
     # ---- configuration
     def set_stream(self, hip_stream: int | None):
-        self._chk(self.L.lumahip_set_stream(self.h, hip_stream))
+        """hip_stream: a hipStream_t handle (0 = the default stream, as torch's default stream reports);
+        None = back to the context's own stream"""
+        if hip_stream is None:
+            self._chk(self.L.lumahip_reset_stream(self.h))
+        else:
+            self._chk(self.L.lumahip_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def sync(self):
         self._chk(self.L.lumahip_sync(self.h))
@@ -260,6 +269,12 @@ class Context:
             self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides), _arr3(C.c_size_t, plane_frame_strides),
             nframes, w, h, profile, sc, rgb_ptr, frame_stride, rgba_ptr, rgba_stride, rgba_frame_stride, exposure, gamma,
             int(bool(do_tmo)), int(bool(ldr_sim))))
+
+    def quantize_array_device(self, in_ptr, out_ptr, n, ch=0):
+        self._chk(self.L.lumahip_quantize_array_device(self.h, in_ptr, out_ptr, n, ch))
+
+    def dequantize_array_device(self, in_ptr, out_ptr, n, ch=0):
+        self._chk(self.L.lumahip_dequantize_array_device(self.h, in_ptr, out_ptr, n, ch))
 
     def transform_frames_device(self, ptr, frame_stride, nframes, w, h, to_cs, sc):
         self._chk(self.L.lumahip_transform_color_space_device(self.h, ptr, frame_stride, nframes, w, h,

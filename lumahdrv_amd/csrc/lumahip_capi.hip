@@ -141,7 +141,15 @@ extern "C" int lumahip_set_stream(lumahip_ctx *c, void *s)
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;  // NULL is a valid handle: the device's default (null) stream
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_reset_stream(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    c->stream = c->own_stream;
     return LUMAHIP_OK;
 }
 
@@ -173,6 +181,12 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     c->idx = build_lut_index(lut, (int)n);
+    if (getenv("LUMAHIP_FORCE_LITERAL") && c->idx.mode == LUT_BUCKET_LDS) {
+        // test hook: run the reference's bisection literally even though the table qualifies for the bucketed
+        // search (tests/test_gpu_exhaustive.py compares the two over every fp32 bit pattern)
+        c->idx = LutIndex();
+        c->idx.mode = LUT_LITERAL_LDS;
+    }
     const LutIndex &ix = c->idx;
     const size_t lut_floats = ((n + std::max(ix.pad, 1)) + 3) & ~(size_t)3;
     std::vector<float> padded(lut_floats, __builtin_nanf(""));
@@ -745,6 +759,8 @@ extern "C" int lumahip_transform_color_space_host(lumahip_ctx *c, float *frame, 
     return LUMAHIP_OK;
 }
 
+static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant);
+
 static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch, bool quant)
 {
     if (!c || !in || !out)
@@ -758,10 +774,38 @@ static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsig
     if (rc)
         return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_arr, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = array_launch(c, c->d_arr, c->d_arr + n, n, ch, quant)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_arr + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantize_array_device(lumahip_ctx *c, const float *in_dev, float *out_dev, size_t n, unsigned ch)
+{
+    if (!c || !in_dev || !out_dev)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return n ? array_launch(c, in_dev, out_dev, n, ch, true) : LUMAHIP_OK;
+}
+
+extern "C" int lumahip_dequantize_array_device(lumahip_ctx *c, const float *in_dev, float *out_dev, size_t n, unsigned ch)
+{
+    if (!c || !in_dev || !out_dev)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return n ? array_launch(c, in_dev, out_dev, n, ch, false) : LUMAHIP_OK;
+}
+
+static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant)
+{
+    HIPCHK(c, hipSetDevice(c->device));
     QArrArgs a{};
     a.q = c->q;
-    a.in = c->d_arr;
-    a.out = c->d_arr + n;
+    a.in = d_in;
+    a.out = d_out;
     a.n = n;
     // src/luma_quantizer.cpp:219,251: LUT path for ch 0 and for every channel of RGB / XYZ
     a.lut_channel = (ch == 0 || c->q.cs == CS_RGB || c->q.cs == CS_XYZ) ? 1 : 0;
@@ -782,8 +826,6 @@ static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsig
         hipLaunchKernelGGL(k_dequantize_array, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->d_arr + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
 }
 
