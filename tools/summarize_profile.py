@@ -29,7 +29,7 @@ def load(path):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     wl = sys.argv[2] if len(sys.argv) > 2 else "pq11_luv"
-    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + (sys.argv[3] if len(sys.argv) > 3 else tag))
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
