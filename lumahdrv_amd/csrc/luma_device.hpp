@@ -119,6 +119,21 @@ LH_DEV float pq_decode(float val, const XformConst &k)
     return k.Lmax * powf_glibc(div_ieee(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw);
 }
 
+// the same two functions on the branch-free powf; `slow` is raised when any argument left its domain
+LH_DEV float pq_encode_r(float val, const XformConst &k, bool &slow)
+{
+    const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
+    const float Lp = powf_regular(div_ieee(val, k.Lmax), n, *k.pw, slow);
+    return powf_regular(div_ieee(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, slow);
+}
+
+LH_DEV float pq_decode_r(float val, const XformConst &k, bool &slow)
+{
+    const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
+    const float Vp = powf_regular(val, 1.0f / m, *k.pw, slow);
+    return k.Lmax * powf_regular(div_ieee(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, slow);
+}
+
 template <int CS>
 LH_DEV void xform_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2);
 
@@ -184,16 +199,35 @@ LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, f
 }
 
 // RGB -> Y'CbCr (BT.2020, PQ): src/luma_quantizer.cpp:317-354
+template <bool REGULAR>
+LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2, bool &slow)
+{
+    float R, G, B;
+    if constexpr (REGULAR) {
+        R = pq_encode_r(std_max(r, 1e-10f), k, slow);
+        G = pq_encode_r(std_max(g, 1e-10f), k, slow);
+        B = pq_encode_r(std_max(b, 1e-10f), k, slow);
+    } else {
+        R = pq_encode(std_max(r, 1e-10f), k);
+        G = pq_encode(std_max(g, 1e-10f), k);
+        B = pq_encode(std_max(b, 1e-10f), k);
+    }
+    const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
+    const float yv = div_ieee(219.0f * y + 16.0f, 255.0f);
+    c0 = REGULAR ? pq_decode_r(yv, k, slow) : pq_decode(yv, k);
+    c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
+    c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
+}
+
+// Straight-line evaluation first; the (rare) pixel with a NaN / inf / denormal / out-of-range power argument
+// is redone with the complete powf.  Both produce identical bits wherever the straight-line form applies.
 template <>
 LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    const float R = pq_encode(std_max(r, 1e-10f), k);
-    const float G = pq_encode(std_max(g, 1e-10f), k);
-    const float B = pq_encode(std_max(b, 1e-10f), k);
-    const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
-    c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
-    c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
-    c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
+    bool slow = false;
+    ycbcr_fwd<true>(r, g, b, k, c0, c1, c2, slow);
+    if (__builtin_expect(slow, 0))
+        ycbcr_fwd<false>(r, g, b, k, c0, c1, c2, slow);
 }
 
 template <int CS>
@@ -208,10 +242,10 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 }
 
 // Y'CbCr -> RGB: src/luma_quantizer.cpp:436-473
-template <>
-LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+template <bool REGULAR>
+LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, bool &slow)
 {
-    float y = pq_encode(c0, k);
+    float y = REGULAR ? pq_encode_r(c0, k, slow) : pq_encode(c0, k);
     y = div_ieee(255.0f * y - 16.0f, 219.0f);
     float blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
     float red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
@@ -219,9 +253,24 @@ LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst 
     red = std_max(0.0f, std_min(1.0f, red));
     green = std_max(0.0f, std_min(1.0f, green));
     blue = std_max(0.0f, std_min(1.0f, blue));
-    r = pq_decode(red, k);
-    g = pq_decode(green, k);
-    b = pq_decode(blue, k);
+    if constexpr (REGULAR) {
+        r = pq_decode_r(red, k, slow);
+        g = pq_decode_r(green, k, slow);
+        b = pq_decode_r(blue, k, slow);
+    } else {
+        r = pq_decode(red, k);
+        g = pq_decode(green, k);
+        b = pq_decode(blue, k);
+    }
+}
+
+template <>
+LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
+{
+    bool slow = false;
+    ycbcr_inv<true>(c0, c1, c2, k, r, g, b, slow);
+    if (__builtin_expect(slow, 0))
+        ycbcr_inv<false>(c0, c1, c2, k, r, g, b, slow);
 }
 
 // XYZ -> RGB (before the final /sc): src/luma_quantizer.cpp:378-395 (matrix include/luma/luma_quantizer.h:84-87)
