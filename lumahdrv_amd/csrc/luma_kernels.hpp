@@ -69,8 +69,6 @@ struct DecArgs {
     int do_tmo, ldr_sim;
 };
 
-constexpr int LDS_ALIGN = 16;
-
 // LDS layout: [lut: lut_len+pad floats, rounded to 16 B][bucket: nbuckets u16, rounded to 16 B][powf tables]
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
 LH_DEV int lds_bucket_bytes(const QuantDev &q) { return (q.nbuckets * 2 + 15) & ~15; }

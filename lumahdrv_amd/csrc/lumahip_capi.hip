@@ -226,11 +226,11 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     return LUMAHIP_OK;
 }
 
-static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket, bool force_global = false)
+static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket)
 {
     const QuantDev &q = c->q;
     size_t b = 0;
-    if (q.mode != LUT_LITERAL_GLOBAL && !force_global) {
+    if (q.mode != LUT_LITERAL_GLOBAL) {
         b += ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
         if (need_bucket && q.mode == LUT_BUCKET_LDS)
             b += ((size_t)q.nbuckets * 2 + 15) & ~(size_t)15;
@@ -337,15 +337,12 @@ static void make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsi
     g.totalTiles = g.tilesPerFrame * (int)nframes;
 }
 
-template <typename K>
-static int grid_for(lumahip_ctx *c, K kern, int threads, size_t lds, int total_tiles)
+// Persistent workgroups, but deliberately MORE of them than fit at once (8 x 256 threads per CU requested, 5-6
+// resident at 80-96 VGPRs): the surplus is dispatched as resident ones retire, which evens out the tail; measured
+// 3-6 % faster than an occupancy-sized grid (tools/tune.py).  LUMAHIP_BLOCKS_PER_CU overrides for experiments.
+static int grid_for(const lumahip_ctx *c, int threads, int total_tiles)
 {
-    // Persistent workgroups, but deliberately MORE of them than fit at once (8 x 256 threads per CU requested,
-    // ~5 resident at 96 VGPRs): the surplus is dispatched as resident ones retire, which evens out the tail;
-    // measured 3-6 % faster than an occupancy-sized grid (tools/tune.py, profiles/r01_tune.txt).
-    (void)kern;
-    (void)lds;
-    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
     long g = (long)c->num_cu * per_cu;
     if (g > total_tiles)
         g = total_tiles;
@@ -409,7 +406,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     const size_t lds = lds_bytes(c, true);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, kern, threads, lds, a.g.totalTiles);
+    const int grid = grid_for(c, threads, a.g.totalTiles);
     if (stats)
         hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
@@ -475,7 +472,7 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     const size_t lds = lds_bytes(c, false);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, kern, threads, lds, a.g.totalTiles);
+    const int grid = grid_for(c, threads, a.g.totalTiles);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
@@ -813,8 +810,6 @@ static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t 
     if (grid > (long)c->num_cu * 8)
         grid = (long)c->num_cu * 8;
     if (quant) {
-        QuantDev saved = a.q;
-        (void)saved;
         size_t lds = 0;
         if (c->q.mode != LUT_LITERAL_GLOBAL) {
             lds = ((size_t)(c->q.lut_len + c->q.pad) * 4 + 15) & ~(size_t)15;
