@@ -318,3 +318,45 @@ def test_decode_display_transform(L, oracle_mod, do_tmo, ldr_sim, exposure, gamm
     for c in range(3):
         assert np.max(np.abs(got[..., c] - exp[c])) <= 1, c
     assert np.mean(got[..., :3] == np.moveaxis(exp, 0, -1)) > 0.98
+
+
+def test_python_host_mirror_of_the_reference_interface(L, oracle_mod):
+    """lumahdrv_amd.LumaFrameCodec / LumaQuantizer (the Python mirror of LumaEncoder::encode, LumaDecoder::decode and
+    LumaQuantizer): defaults of the reference's parameter structs, profile adjustment, pack-only / unpack-only
+    (setChannels / getVpxChannels on their own), decoder-style mapping override."""
+    o = oracle_mod
+    p = L.LumaEncoderParams()
+    assert (p.ptfBitDepth, p.colorBitDepth, p.preScaling, p.profile, p.bitDepth, p.ptf, p.colorSpace) == (11, 8, 1.0, 2, 12, L.PTF_PQ, L.CS_LUV)
+    assert L.LumaDecoderParams().ptf == L.PTF_PSI           # include/luma/luma_decoder.h:62
+    codec = L.LumaFrameCodec(p)
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    f = o.test_frame(128, 64)
+    planes, st, mean = codec.encode(f)
+    e, _, avg = orc.encode(f.copy(), 1.0, 2)
+    assert all(np.array_equal(a, b) for a, b in zip(planes, e)) and mean == pytest.approx(avg, rel=1e-3)
+    assert same_bits(codec.decode(planes, st, 128, 64), orc.decode(e, st, 128, 64, 1.0, 2))
+    # bitDepth 8 moves profile 2 -> 0 (src/luma_encoder.cpp:68-72)
+    p8 = L.LumaEncoderParams(bitDepth=8, ptfBitDepth=8)
+    c8 = L.LumaFrameCodec(p8)
+    assert c8.params.profile == 0
+    pl8, st8, _ = c8.encode(f)
+    e8, _, _ = o.Oracle(o.PTF_PQ, 8, o.CS_LUV, 8, 1e4, 0.005).encode(f.copy(), 1.0, 0)
+    assert all(np.array_equal(a, b) for a, b in zip(pl8, e8))
+    # setChannels / getVpxChannels on their own == the oracle's pack / unpack of an already transformed frame
+    q = codec.quant
+    g = f.copy()
+    assert q.transformColorSpace(g, True, 1.0)
+    packed, pst, _ = q.ctx.pack_frame(g, 2)
+    assert all(np.array_equal(a, b) for a, b in zip(packed, e))
+    un = q.ctx.unpack_frame(packed, pst, 128, 64, 2)
+    exp = np.empty_like(un)
+    import ctypes as C
+    for pl in range(3):
+        orc.L.lo_unpack_plane(C.byref(orc.q), e[pl].ctypes.data, st[pl], pl, 2, 128, 64, exp[pl].ctypes.data)
+    assert same_bits(un, exp)
+    assert q.getSize() == 2047 and q.getMapping().size == 2048 and q.getMaxLum() == 1e4
+    # decoder-style override: attachment 434 carries getSize() floats, the last entry stays this side's
+    q2 = L.LumaQuantizer()
+    ov = (q.getMapping()[:-1] * np.float32(1.5)).astype(np.float32)
+    q2.setQuantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, mapping_override=ov)
+    assert q2.getMapping()[-1] == q.getMapping()[-1] and q2.getMapping()[5] == ov[5]
