@@ -1,9 +1,8 @@
 // luma_quantizer.h -- LumaQuantizer with the reference's public interface
 // (include/luma/luma_quantizer.h:89-126 there), implemented on the MI355X through the C ABI of
-// include/lumahip.h.  Frame-level work (transformColorSpace) runs as HIP kernels; the per-value
-// quantize()/dequantize() members are the scalar convenience API the reference exposes (lumaplay and the
-// encoder loops call them per sample) and are evaluated on the host from the same table -- the frame path
-// never goes through them.
+// include/lumahip.h.  Everything that touches pixel values runs as HIP kernels -- including the per-value
+// quantize()/dequantize() members (one-element launches of the array kernels: API parity, not a fast path).
+// Only the construction of the transfer-function table stays on the host, as in the reference.
 #ifndef LUMA_HIP_QUANTIZER_H
 #define LUMA_HIP_QUANTIZER_H
 

@@ -2,8 +2,6 @@
 // as the reference does) and uploaded with lumahip_set_quantizer; transformColorSpace runs on the GPU.
 #include "../../../include/luma/luma_quantizer.h"
 
-#include <algorithm>
-#include <cmath>
 #include <cstdio>
 
 #include "../../../include/luma/luma_exception.h"
@@ -87,37 +85,28 @@ void LumaQuantizer::syncMapping()
         throw LumaException(lumahip_last_error(m_ctx));
 }
 
-// Scalar convenience API (the reference's per-sample entry points); same decisions as the reference:
-// bisection + nearest-of-two on the table, floor(maxC*v + 0.5) clamped for colour channels.
+// Per-value API of the reference (its own plane loops call these per sample; nothing in this library does).
+// Evaluated by the same GPU kernels as the array forms -- one-element launches: slow per call, but there is no
+// pixel arithmetic on the CPU anywhere in the product.  Use the frame-level calls (or
+// lumahip_quantize_array_host) for bulk work.
 float LumaQuantizer::quantize(const float val, const unsigned int ch) const
 {
-    if (ch == 0 || m_colorSpace == CS_RGB || m_colorSpace == CS_XYZ) {
-        int lo = 0, hi = (int)m_maxVal;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) / 2;
-            if (val < m_mapping[mid])
-                hi = mid;
-            else
-                lo = mid;
-        }
-        return (val - m_mapping[lo] < m_mapping[hi] - val) ? (float)lo : (float)hi;
-    }
-    const float top = (float)m_maxValColor;
-    float r = std::floor(top * val + 0.5f);
-    r = std::min(top, r);
-    return std::max(0.0f, r);
+    if (!m_configured)
+        throw LumaException("LumaQuantizer::quantize before setQuantizer");
+    float out = 0.0f;
+    if (lumahip_quantize_array_host(m_ctx, &val, &out, 1, ch) != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_ctx));
+    return out;
 }
 
 float LumaQuantizer::dequantize(const float val, const unsigned int ch) const
 {
-    if (ch == 0 || m_colorSpace == CS_RGB || m_colorSpace == CS_XYZ) {
-        if (val < 0)
-            return m_mapping[0];
-        if (val >= m_maxVal)
-            return m_mapping[m_maxVal];
-        return m_mapping[(int)val];
-    }
-    return std::max(val / m_maxValColor, 1e-10f);
+    if (!m_configured)
+        throw LumaException("LumaQuantizer::dequantize before setQuantizer");
+    float out = 0.0f;
+    if (lumahip_dequantize_array_host(m_ctx, &val, &out, 1, ch) != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_ctx));
+    return out;
 }
 
 bool LumaQuantizer::transformColorSpace(LumaFrame *frame, bool toCs, float sc)

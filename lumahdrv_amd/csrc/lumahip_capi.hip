@@ -325,7 +325,7 @@ static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile)
     return LUMAHIP_OK;
 }
 
-static void make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes)
+static bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes)
 {
     g.w = (int)w;
     g.h = (int)h;
@@ -334,7 +334,11 @@ static void make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsi
     g.tilesX = (g.unitsX + 63) / 64;
     g.tilesY = (g.unitsY + nw - 1) / nw;
     g.tilesPerFrame = g.tilesX * g.tilesY;
-    g.totalTiles = g.tilesPerFrame * (int)nframes;
+    const long long total = (long long)g.tilesPerFrame * nframes;
+    if (w > 0x7fffffffu / 4 || h > 0x7fffffffu / 4 || total > 0x7fffffffLL)
+        return false;  // tile indices are 32-bit
+    g.totalTiles = (int)total;
+    return true;
 }
 
 // Persistent workgroups, but deliberately MORE of them than fit at once (8 x 256 threads per CU requested, 5-6
@@ -383,7 +387,8 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     EncArgs a{};
     a.q = c->q;
     const int threads = c->block_threads;
-    make_geom(a.g, w, h, vw, threads / 64, nframes);
+    if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     a.src = rgb;
     a.frame_stride = frame_stride;
     a.sc = sc;
@@ -443,7 +448,8 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     DecArgs a{};
     a.q = c->q;
     const int threads = c->block_threads;
-    make_geom(a.g, w, h, vw, threads / 64, nframes);
+    if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     a.dst = rgb;
     a.frame_stride = frame_stride;
     a.sc = sc;
