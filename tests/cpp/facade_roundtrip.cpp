@@ -89,7 +89,7 @@ int main(int argc, char **argv)
         printf("Decoding finished. %d frames decoded. size %u\n", n, decoder.getQuantizer()->getSize());
         // per-value API (GPU one-element launches): PQ-11 pins of SURVEY.md 8(c) when the table is PQ-11
         LumaQuantizer *q = decoder.getQuantizer();
-        printf("scalar %g %g %g %g\n", q->quantize(1.0f, 0), q->quantize(100.0f, 0), q->quantize(0.3f, 1),
+        printf("scalar %.9g %.9g %.9g %.9g\n", q->quantize(1.0f, 0), q->quantize(100.0f, 0), q->quantize(0.3f, 1),
                q->dequantize(307.0f, 0));
         // error conventions
         try {
