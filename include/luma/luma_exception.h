@@ -1,20 +1,15 @@
-// luma_exception.h -- error type thrown by the facade's initialize()/decode() paths, same name and
-// interface as the reference's (include/luma/luma_exception.h:53-71 there): std::exception + what().
+// luma_exception.h -- the error type the facade throws from initialize() / encode() / decode().
+// Interface contract taken from the reference (include/luma/luma_exception.h:53-71 there): constructible from a
+// C string, catchable as std::exception, what() returns the message.  Implemented on std::runtime_error.
 #ifndef LUMA_HIP_EXCEPTION_H
 #define LUMA_HIP_EXCEPTION_H
 
-#include <exception>
+#include <stdexcept>
 #include <string>
 
-class LumaException : public std::exception {
-public:
-    explicit LumaException(const char *message) : m_what(message ? message : "") {}
-    explicit LumaException(const std::string &message) : m_what(message) {}
-    ~LumaException() throw() {}
-    const char *what() const throw() { return m_what.c_str(); }
-
-private:
-    std::string m_what;
+struct LumaException : std::runtime_error {
+    explicit LumaException(const char *message) : std::runtime_error(message ? message : "unknown Luma HDRv error") {}
+    explicit LumaException(const std::string &message) : std::runtime_error(message) {}
 };
 
 #endif

@@ -1,24 +1,32 @@
 // luma_frame.h -- planar fp32 frame, the boundary type of the hot path.
-// Same public members and layout as the reference's LumaFrame (include/luma/luma_frame.h:51-90 there):
-// `buffer` holds channels*height*width floats, channel c starts at buffer + c*height*width, rows are
-// `width` floats, no padding.  Written from scratch for this repo.
+//
+// Layout contract (the reference's LumaFrame, include/luma/luma_frame.h:51-90 there, which every caller and both
+// I/O adapters rely on): public `width`, `height`, `channels`, `buffer`; `buffer` holds channels*height*width floats,
+// channel c starts at buffer + c*height*width, rows are `width` floats, no padding; init() (re)allocates for the
+// current dimensions, clear() releases, getChannel(c) returns the plane pointer.  Written from scratch here.
 #ifndef LUMA_HIP_FRAME_H
 #define LUMA_HIP_FRAME_H
 
 #include <cstddef>
 
 struct LumaFrame {
-    explicit LumaFrame(unsigned int w = 0, unsigned int h = 0, unsigned int c = 3)
-        : height(h), width(w), channels(c), buffer(NULL)
+    unsigned int height = 0, width = 0, channels = 3;
+    float *buffer = NULL;
+
+    LumaFrame() {}
+    LumaFrame(unsigned int w, unsigned int h, unsigned int c = 3) : height(h), width(w), channels(c)
     {
-        if (w != 0 && h != 0 && c != 0)
+        if (pixelCount() != 0)
             init();
     }
     ~LumaFrame() { clear(); }
 
-    // frames own their storage; copying would double-free, exactly as in the reference, so forbid it here
+    // a frame owns its storage; a copy would free it twice (as it would in the reference), so copying is disabled
     LumaFrame(const LumaFrame &) = delete;
     LumaFrame &operator=(const LumaFrame &) = delete;
+
+    size_t planeSize() const { return (size_t)height * width; }
+    size_t pixelCount() const { return planeSize() * channels; }
 
     void clear()
     {
@@ -26,22 +34,20 @@ struct LumaFrame {
         buffer = NULL;
     }
 
-    // (re)allocates for the current width/height/channels.  The reference refuses only when ALL three are
-    // zero (its guard uses &&); a frame with one zero dimension gets an empty buffer.
+    // The reference refuses only when width, height AND channels are all zero; a frame with a
+    // single zero dimension gets an empty allocation.  Same here.
     bool init()
     {
-        if (height == 0 && width == 0 && channels == 0)
+        const bool nothingSet = (height | width | channels) == 0;
+        if (nothingSet)
             return false;
         clear();
-        buffer = new float[(size_t)channels * height * width];
+        buffer = new float[pixelCount()];
         return true;
     }
 
-    float *getChannel(unsigned int c) { return buffer + (size_t)c * height * width; }
-    const float *getChannel(unsigned int c) const { return buffer + (size_t)c * height * width; }
-
-    unsigned int height, width, channels;
-    float *buffer;
+    float *getChannel(unsigned int c) { return buffer + c * planeSize(); }
+    const float *getChannel(unsigned int c) const { return buffer + c * planeSize(); }
 };
 
 #endif

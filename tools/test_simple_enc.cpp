@@ -1,59 +1,91 @@
-// tools/test_simple_enc.cpp -- counterpart of the reference's test/test_simple_enc.cpp (same arguments,
-// same parameter set, same progress lines) on the MI355X facade.
-//   test_simple_enc <hdr_frames printf pattern> <start_frame> <end_frame> <output>
-// Without arguments five synthetic test frames (1280x720) are encoded into "output.lhs" (a raw Y/U/V plane
-// stream with the reference's metadata attachments; the VP9 + Matroska stages are out of scope).
+// tools/test_simple_enc.cpp -- the MI355X counterpart of the reference's minimal encoder example
+// (test/test_simple_enc.cpp there): same command line, same parameter set, same progress lines.
+//
+//   test_simple_enc [<hdr_frames printf pattern> [<start_frame> [<end_frame> [<output>]]]]
+//
+// With no arguments frames 1..5 are the synthetic 1280x720 test pattern and the stream goes to "output.lhs" --
+// a raw Y/U/V plane stream carrying the reference's metadata attachments (VP9 + Matroska are out of scope).
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
+#include <string>
 
 #include "exr_interface.h"
 #include "luma/luma_encoder.h"
 
+namespace {
+
+struct Options {
+    std::string pattern;  // empty: synthetic test frames
+    int first = 1, last = 5;
+    std::string output = "output.lhs";
+};
+
+bool wantsHelp(int argc, char **argv)
+{
+    return argc > 1 && (std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help");
+}
+
+Options parse(int argc, char **argv)
+{
+    Options o;
+    if (argc > 1) o.pattern = argv[1];
+    if (argc > 2) o.first = std::atoi(argv[2]);
+    if (argc > 3) o.last = std::atoi(argv[3]);
+    if (argc > 4) o.output = argv[4];
+    return o;
+}
+
+// the parameter set of the reference example: 12-bit VP9 profile 2, PQ 11 bits, Lu'v' with 8-bit chroma
+LumaEncoderParams exampleParams(LumaEncoderParams p)
+{
+    p.profile = 2;
+    p.bitDepth = 12;
+    p.ptf = LumaQuantizer::PTF_PQ;
+    p.ptfBitDepth = 11;
+    p.colorSpace = LumaQuantizer::CS_LUV;
+    p.colorBitDepth = 8;
+    p.quantizerScale = 4;
+    p.bitrate = 1000;
+    p.keyframeInterval = 0;
+    p.lossLess = false;
+    return p;
+}
+
+void loadFrame(const Options &o, int index, LumaFrame &frame)
+{
+    if (o.pattern.empty()) {
+        ExrInterface::testFrame(frame);
+        return;
+    }
+    char path[1024];
+    std::snprintf(path, sizeof path, o.pattern.c_str(), index);
+    ExrInterface::readFrame(path, frame);
+}
+
+}  // namespace
+
 int main(int argc, char *argv[])
 {
-    if (argc > 1 && (!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help"))) {
-        printf("Usage: ./test_simple_enc <hdr_frames> <start_frame> <end_frame> <output>\n");
+    if (wantsHelp(argc, argv)) {
+        std::printf("Usage: ./test_simple_enc <hdr_frames> <start_frame> <end_frame> <output>\n");
         return 1;
     }
-    const char *hdrFrames = argc > 1 ? argv[1] : NULL;
-    const int startFrame = argc > 2 ? atoi(argv[2]) : 1;
-    const int endFrame = argc > 3 ? atoi(argv[3]) : 5;
-    const char *outputFile = argc > 4 ? argv[4] : "output.lhs";
-
+    const Options opt = parse(argc, argv);
     try {
         LumaEncoder encoder;
-        LumaEncoderParams params = encoder.getParams();
-        params.profile = 2;
-        params.bitrate = 1000;
-        params.keyframeInterval = 0;
-        params.bitDepth = 12;
-        params.ptfBitDepth = 11;
-        params.colorBitDepth = 8;
-        params.lossLess = 0;
-        params.quantizerScale = 4;
-        params.ptf = LumaQuantizer::PTF_PQ;
-        params.colorSpace = LumaQuantizer::CS_LUV;
-        encoder.setParams(params);
-
-        char name[500];
-        for (int f = startFrame; f <= endFrame; f++) {
-            printf("Encoding frame %d.\n", f);
+        encoder.setParams(exampleParams(encoder.getParams()));
+        for (int f = opt.first; f <= opt.last; ++f) {
+            std::printf("Encoding frame %d.\n", f);
             LumaFrame frame;
-            if (hdrFrames != NULL) {
-                snprintf(name, sizeof name, hdrFrames, f);
-                ExrInterface::readFrame(name, frame);
-            } else {
-                ExrInterface::testFrame(frame);
-            }
+            loadFrame(opt, f, frame);
             if (!encoder.initialized())
-                encoder.initialize(outputFile, frame.width, frame.height);
+                encoder.initialize(opt.output.c_str(), frame.width, frame.height);
             encoder.encode(&frame);
         }
         encoder.finish();
-        printf("Encoding finished. %d frames encoded.\n", endFrame - startFrame + 1);
-    } catch (LumaException &e) {
-        fprintf(stderr, "\nError: %s\n", e.what());
+        std::printf("Encoding finished. %d frames encoded.\n", opt.last - opt.first + 1);
+    } catch (const LumaException &e) {
+        std::fprintf(stderr, "\nError: %s\n", e.what());
         return 1;
     }
     return 0;
