@@ -19,7 +19,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_lut_index_host", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
@@ -85,6 +85,7 @@ def lib():
     L.lumahip_sync.argtypes = [vp]
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
+    L.lumahip_lut_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
@@ -130,6 +131,17 @@ def build_lut(ptf: int, bitdepth: int, max_lum: float = 1e4, min_lum: float = 0.
     if rc != OK:
         raise LumaHipError(rc, "lumahip_build_lut(ptf=%d, bitdepth=%d) failed" % (ptf, bitdepth))
     return out
+
+
+def lut_index(lut: np.ndarray):
+    """host-only: (mode, shift, kmin, steps, start[]) of the bucketed search index for a table (no GPU needed)"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    info = (C.c_int * 4)()
+    start = np.zeros(8192, dtype=np.uint16)
+    rc = lib().lumahip_lut_index_host(lut.ctypes.data, lut.size, info, start.ctypes.data, start.size)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_lut_index_host failed")
+    return dict(mode=info[0], shift=info[1], kmin=info[2], steps=info[3], start=start)
 
 
 def _arr3(ctype, vals):

@@ -226,6 +226,24 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     return LUMAHIP_OK;
 }
 
+// host-only view of the search index (no GPU, no context): what lumahip_set_quantizer would build for this table
+extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[4], uint16_t *start_out, size_t start_cap)
+{
+    if (!lut || !info || n < 2 || n > 65536)
+        return LUMAHIP_ERR_ARG;
+    const LutIndex ix = build_lut_index(lut, (int)n);
+    info[0] = ix.mode;
+    info[1] = ix.shift;
+    info[2] = ix.kmin;
+    info[3] = ix.steps;
+    if (start_out) {
+        if (start_cap < ix.start.size())
+            return LUMAHIP_ERR_ARG;
+        memcpy(start_out, ix.start.data(), ix.start.size() * sizeof(uint16_t));
+    }
+    return (int)ix.start.size() >= 0 ? LUMAHIP_OK : LUMAHIP_ERR_ARG;
+}
+
 static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket)
 {
     const QuantDev &q = c->q;
