@@ -184,6 +184,15 @@ def main():
             ms.append(ctx.time_launches(0, 1, s_i, n3, B, w, h, sc, profile, pl_i, st, psz))
         avg_ms = float(np.mean(ms))
         achieved = BYTES_PER_PIXEL * px_step / (avg_ms * 1e-3) / 1e9
+        probe_ms = None
+        if profile == 2 and w % 4 == 0:
+            # the same loads and stores with no arithmetic: what the memory system gives this traffic mix here.
+            # (overwrites the planes of these batches; they are re-encoded by nothing afterwards)
+            pm = []
+            for i in range(iters):
+                s_i, _, pl_i = ptrs(i % nbatch)
+                pm.append(ctx.probe_encode_traffic(s_i, n3, B, w, h, pl_i, st, psz))
+            probe_ms = float(np.mean(pm))
         traffic = None
         try:
             with open(args.traffic_json) as f:
@@ -196,6 +205,8 @@ def main():
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel": kname, "kernel_ms": round(avg_ms, 4),
                            "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
+                           "traffic_only_ms": None if probe_ms is None else round(probe_ms, 4),
+                           "frac_of_traffic_only_rate": None if probe_ms is None else round(probe_ms / avg_ms, 3),
                            "decode_achieved_GBs": round(BYTES_PER_PIXEL * K * px_step / t_dec / 1e9, 1)}
 
     # ---- CPU baseline: the oracle (port of the reference's scalar loops) on this host, bounded sample

@@ -180,6 +180,13 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
 int lumahip_host_register(lumahip_ctx *ctx, void *host_ptr, size_t bytes);
 int lumahip_host_unregister(lumahip_ctx *ctx, void *host_ptr);
 
+/* Benchmark probe: the loads and stores of the 4:2:0 16-bit encode kernel with no arithmetic in between (same
+ * tile order, same access widths, non-temporal), `iters` launches, average milliseconds.  OVERWRITES the planes
+ * with garbage.  What the memory system alone needs for the encode traffic mix on this device. */
+int lumahip_probe_encode_traffic_device(lumahip_ctx *ctx, const float *rgb_dev, size_t frame_stride, unsigned nframes,
+                                        unsigned w, unsigned h, unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], int iters, float *avg_ms);
+
 /* ---- device memory helpers (for hosts without their own allocator, e.g. the C++ facade) -------- */
 int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
 int lumahip_free(lumahip_ctx *ctx, void *dev_ptr);

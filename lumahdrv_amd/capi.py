@@ -24,7 +24,7 @@ SYMBOLS = [
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
-    "lumahip_time_launches", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
     L.lumahip_transform_color_space_device.argtypes = [vp, vp, sz, u, u, u, i, f]
     L.lumahip_synth_frames_device.argtypes = [vp, vp, sz, u, u, u, C.c_uint64, C.c_uint64]
     L.lumahip_time_launches.argtypes = [vp, i, i, vp, sz, u, u, u, f, i, pp3, ip3, sp3, C.POINTER(f)]
+    L.lumahip_probe_encode_traffic_device.argtypes = [vp, vp, sz, u, u, u, pp3, ip3, sp3, i, C.POINTER(f)]
     L.lumahip_host_register.argtypes = [vp, vp, sz]
     L.lumahip_host_unregister.argtypes = [vp, vp]
     L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
@@ -302,6 +303,15 @@ class Context:
         self._chk(self.L.lumahip_time_launches(self.h, direction, iters, rgb_ptr, frame_stride, nframes, w, h, sc,
                                                profile, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
                                                _arr3(C.c_size_t, plane_frame_strides), C.byref(ms)))
+        return float(ms.value)
+
+    def probe_encode_traffic(self, rgb_ptr, frame_stride, nframes, w, h, plane_ptrs, strides, plane_frame_strides,
+                             iters=1) -> float:
+        """ms per launch of the encode kernel's loads + stores without arithmetic (overwrites the planes)"""
+        ms = C.c_float(0)
+        self._chk(self.L.lumahip_probe_encode_traffic_device(self.h, rgb_ptr, frame_stride, nframes, w, h,
+                                                             _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                             _arr3(C.c_size_t, plane_frame_strides), iters, C.byref(ms)))
         return float(ms.value)
 
     def host_register(self, arr: np.ndarray):

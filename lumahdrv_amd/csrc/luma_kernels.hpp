@@ -459,6 +459,39 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         stats_flush(st, a.stats, tx);
 }
 
+// Traffic probe: the loads and stores of k_encode<.,4:2:0,VW=4> for 16-bit planes with NO arithmetic (an xor
+// keeps every loaded word live).  Its run time is what the memory system alone needs for the encode traffic mix
+// (12 B read + 3 B written per pixel, same tile order, same non-temporal accesses); bench.py reports the encode
+// kernel's time as a fraction of it next to the fraction of the 8 TB/s peak.
+__global__ __launch_bounds__(256) void k_encode_traffic_probe(const EncArgs a)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const size_t cs = (size_t)a.g.w * a.g.h;
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
+        int f, bx, by;
+        tile_coords(t, a.g, f, bx, by);
+        const int ux = bx * 64 + tx, uy = by * NW + ty;
+        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
+            continue;
+        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * 4;
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                float v[4];
+                load_px<4>(p + c * cs + (size_t)r * a.g.w, v);
+                q0 ^= __float_as_uint(v[0]); q1 ^= __float_as_uint(v[1]); q2 ^= __float_as_uint(v[2]); q3 ^= __float_as_uint(v[3]);
+            }
+        unsigned char *d0 = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * 8;
+        nt_store_u32x2(d0, q0, q1);
+        nt_store_u32x2(d0 + a.stride[0], q2, q3);
+        nt_store_u32(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * 4, q0 ^ q2);
+        nt_store_u32(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * 4, q1 ^ q3);
+    }
+}
+
 // ---- DECODE ---------------------------------------------------------------------------------------
 // GL: LUT read from global memory (bitdepth > 12) instead of LDS.  Same software pipeline as encode: the
 // sample loads of the next unit are issued before the current unit is dequantized and transformed.

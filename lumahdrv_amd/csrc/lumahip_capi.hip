@@ -595,6 +595,49 @@ extern "C" int lumahip_synth_frames_device(lumahip_ctx *c, float *dst, size_t fr
     return LUMAHIP_OK;
 }
 
+extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
+                                                   unsigned w, unsigned h, unsigned char *const planes[3],
+                                                   const int stride[3], const size_t pfs[3], int iters, float *avg_ms)
+{
+    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0 || iters <= 0 || !avg_ms)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (w == 0 || h == 0 || (w % 4) || (h & 1) || !is_aligned(rgb, 16) || (frame_stride % 4))
+        return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs w % 4 == 0, even h and 16-byte aligned frames");
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || !is_aligned(planes[p], 8) || (stride[p] % (p ? 4 : 8)) || (pfs[p] % 8))
+            return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs 8-byte aligned 16-bit 4:2:0 planes");
+    HIPCHK(c, hipSetDevice(c->device));
+    EncArgs a{};
+    const int threads = 256;
+    if (!make_geom(a.g, w, h, 4, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large");
+    a.src = rgb;
+    a.frame_stride = frame_stride;
+    a.bps = 2;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        a.dst[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.dst_frame_stride[p] = pfs[p];
+    }
+    const int grid = grid_for(c, threads, a.g.totalTiles);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_encode_traffic_probe, dim3(grid), dim3(threads), 0, c->stream, a);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(c, hipGetLastError());
+    *avg_ms = ms / iters;
+    return LUMAHIP_OK;
+}
+
 extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const float *rgb, size_t frame_stride,
                                      unsigned nframes, unsigned w, unsigned h, float sc, int profile,
                                      unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
