@@ -115,6 +115,17 @@ int lumahip_encode_frame_host(lumahip_ctx *ctx, const float *rgb, unsigned w, un
 int lumahip_decode_frame_host(lumahip_ctx *ctx, const unsigned char *const planes[3], const int stride[3],
                               unsigned w, unsigned h, int profile, float sc, float *rgb_out);
 
+/* Batched forms of the two calls above for callers that hold several frames (a transcoder, a batch job):
+ * rgb[i] / rgb_out[i] are nframes host frames, planes[3*i + p] the planes of frame i.  Internally a 3-slot pipeline
+ * over three HIP streams: frame i's H2D copy overlaps frame i-1's kernel and frame i-2's D2H copy (fully so when
+ * the caller's buffers are pinned, lumahip_host_register).  Results are identical to nframes single calls.
+ * mean_lum (nullable) receives nframes values. */
+int lumahip_encode_frames_host(lumahip_ctx *ctx, const float *const *rgb, unsigned nframes, unsigned w, unsigned h,
+                               float sc, int profile, unsigned char *const *planes, const int stride[3],
+                               float *mean_lum);
+int lumahip_decode_frames_host(lumahip_ctx *ctx, const unsigned char *const *planes, const int stride[3],
+                               unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const *rgb_out);
+
 /* Replaces LumaEncoder::setChannels(LumaFrame*) on its own (src/luma_encoder.cpp:196-201): quantize + pack a
  * frame that is ALREADY colour-transformed.  And LumaDecoder::getVpxChannels on its own
  * (src/luma_decoder.cpp:205-240): unpack + dequantize without the inverse colour transform. */

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
     "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_lut_index_host", "lumahip_quantizer_info",
-    "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
+    "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
@@ -89,6 +89,8 @@ def lib():
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
+    L.lumahip_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
+    L.lumahip_decode_frames_host.argtypes = [vp, pp3, ip3, u, u, u, i, f, pp3]
     L.lumahip_pack_frame_host.argtypes = [vp, vp, u, u, i, pp3, ip3, C.POINTER(f)]
     L.lumahip_unpack_frame_host.argtypes = [vp, pp3, ip3, u, u, i, vp]
     L.lumahip_transform_color_space_host.argtypes = [vp, vp, u, u, i, f]
@@ -222,6 +224,29 @@ class Context:
         self._chk(self.L.lumahip_decode_frame_host(self.h, _arr3(C.c_void_p, [p.ctypes.data for p in planes]),
                                                    _arr3(C.c_int, strides), w, h, profile, sc, out.ctypes.data))
         return out
+
+    def encode_frames(self, frames, sc=1.0, profile=2, align=32):
+        """pipelined batch form of encode_frame: frames = list of (3,h,w) float32 arrays.  Returns
+        (list of plane triplets, strides, list of mean luminances)."""
+        frames = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+        n = len(frames)
+        _, h, w = frames[0].shape
+        _, hs, st, _ = plane_geometry(w, h, profile, align)
+        planes = [[np.zeros((hs[p], st[p]), dtype=np.uint8) for p in range(3)] for _ in range(n)]
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        pp = (C.c_void_p * (3 * n))(*[pl.ctypes.data for tri in planes for pl in tri])
+        means = (C.c_float * n)()
+        self._chk(self.L.lumahip_encode_frames_host(self.h, fp, n, w, h, sc, profile, pp, _arr3(C.c_int, st), means))
+        return planes, st, [float(m) for m in means]
+
+    def decode_frames(self, planes_list, strides, w, h, sc=1.0, profile=2):
+        n = len(planes_list)
+        planes_list = [[np.ascontiguousarray(p) for p in tri] for tri in planes_list]
+        outs = [np.empty((3, h, w), dtype=np.float32) for _ in range(n)]
+        pp = (C.c_void_p * (3 * n))(*[pl.ctypes.data for tri in planes_list for pl in tri])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self._chk(self.L.lumahip_decode_frames_host(self.h, pp, _arr3(C.c_int, strides), n, w, h, profile, sc, op))
+        return outs
 
     def pack_frame(self, transformed: np.ndarray, profile=2, align=32):
         """LumaEncoder::setChannels on its own: quantize + pack an already colour-transformed frame"""

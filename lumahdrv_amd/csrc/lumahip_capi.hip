@@ -42,6 +42,18 @@ struct lumahip_ctx {
     float *d_arr = nullptr;
     size_t d_arr_cap = 0;
 
+    // 3-slot pipeline of the batched host entry points (H2D / kernel / D2H on three streams)
+    struct Slot {
+        float *d_frame = nullptr;
+        unsigned char *d_planes = nullptr;
+        float *d_stats = nullptr;
+        hipEvent_t h2d = nullptr, kern = nullptr, d2h = nullptr;
+    } slot[3];
+    size_t slot_frame_cap = 0, slot_planes_cap = 0;
+    hipStream_t s_h2d = nullptr, s_kern = nullptr, s_d2h = nullptr;
+    float *h_stats = nullptr;  // pinned, 3 floats per frame
+    size_t h_stats_cap = 0;
+
     int cs_override = -1;  // CS_PACK / CS_RGB while a pack-only / unpack-only call is in flight
     int block_threads = 256;
     int blocks_per_cu = 0;  // 0 = occupancy query
@@ -130,6 +142,18 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_arr);
+    for (auto &sl : c->slot) {
+        (void)hipFree(sl.d_frame);
+        (void)hipFree(sl.d_planes);
+        (void)hipFree(sl.d_stats);
+        if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+        if (sl.kern) (void)hipEventDestroy(sl.kern);
+        if (sl.d2h) (void)hipEventDestroy(sl.d2h);
+    }
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_kern) (void)hipStreamDestroy(c->s_kern);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -783,6 +807,164 @@ extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *co
     HIPCHK(c, hipMemcpyAsync(rgb_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
+}
+
+// ---- batched host entry points: a 3-slot software pipeline over three streams.  Frame i's H2D copy runs while
+// frame i-1's kernel and frame i-2's D2H copies are in flight; with pinned caller memory (lumahip_host_register) the
+// two copy directions overlap as well and the rate approaches the PCIe H2D rate.
+static int pipe_prepare(lumahip_ctx *c, size_t frame_bytes, size_t planes_bytes, unsigned nframes)
+{
+    if (!c->s_h2d) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_kern, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+        for (auto &sl : c->slot) {
+            HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.kern, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.d2h, hipEventDisableTiming));
+            HIPCHK(c, hipMalloc(&sl.d_stats, 3 * sizeof(float)));
+        }
+    }
+    if (c->slot_frame_cap < frame_bytes || c->slot_planes_cap < planes_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &sl : c->slot) {
+            (void)hipFree(sl.d_frame);
+            (void)hipFree(sl.d_planes);
+            sl.d_frame = nullptr;
+            sl.d_planes = nullptr;
+            HIPCHK(c, hipMalloc(&sl.d_frame, frame_bytes));
+            HIPCHK(c, hipMalloc(&sl.d_planes, planes_bytes));
+        }
+        c->slot_frame_cap = frame_bytes;
+        c->slot_planes_cap = planes_bytes;
+    }
+    if (c->h_stats_cap < nframes) {
+        if (c->h_stats)
+            (void)hipHostFree(c->h_stats);
+        c->h_stats = nullptr;
+        HIPCHK(c, hipHostMalloc(&c->h_stats, (size_t)nframes * 3 * sizeof(float), hipHostMallocDefault));
+        c->h_stats_cap = nframes;
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rgb, unsigned nframes, unsigned w, unsigned h,
+                                          float sc, int profile, unsigned char *const *planes, const int stride[3],
+                                          float *mean_lum)
+{
+    if (!c || !rgb || !planes || !stride || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (unsigned i = 0; i < nframes; i++) {
+        if (!rgb[i])
+            return fail(c, LUMAHIP_ERR_ARG, "null frame %u", i);
+        for (int p = 0; p < 3; p++)
+            if (!planes[3 * i + p] || stride[p] < L.row_bytes[p])
+                return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
+    }
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
+        return rc;
+    hipStream_t saved = c->stream;
+    const size_t pfs[3] = {0, 0, 0};
+    for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        if (i >= 3) {
+            // slot reuse: the kernel of frame i-3 must have consumed d_frame, its D2H must have drained d_planes
+            (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);
+            (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
+        }
+        if (hipMemcpyAsync(sl.d_frame, rgb[i], nfl * sizeof(float), hipMemcpyHostToDevice, c->s_h2d) != hipSuccess) {
+            rc = fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+            break;
+        }
+        (void)hipEventRecord(sl.h2d, c->s_h2d);
+        (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+        c->stream = c->s_kern;
+        rc = lumahip_encode_frames_device(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+        c->stream = saved;
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.kern, c->s_kern);
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        for (int p = 0; p < 3; p++)
+            if (hipMemcpy2DAsync(planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p],
+                                 hipMemcpyDeviceToHost, c->s_d2h) != hipSuccess)
+                rc = fail(c, LUMAHIP_ERR_HIP, "D2H copy of frame %u failed", i);
+        (void)hipMemcpyAsync(c->h_stats + 3 * (size_t)i, sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+    }
+    c->stream = saved;
+    HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+    HIPCHK(c, hipStreamSynchronize(c->s_kern));
+    HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+    if (rc == LUMAHIP_OK && mean_lum)
+        for (unsigned i = 0; i < nframes; i++)
+            mean_lum[i] = c->h_stats[3 * (size_t)i] / (float)((int)w * (int)h);
+    return rc;
+}
+
+extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *const *planes, const int stride[3],
+                                          unsigned nframes, unsigned w, unsigned h, int profile, float sc,
+                                          float *const *rgb_out)
+{
+    if (!c || !rgb_out || !planes || !stride || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (unsigned i = 0; i < nframes; i++) {
+        if (!rgb_out[i])
+            return fail(c, LUMAHIP_ERR_ARG, "null output frame %u", i);
+        for (int p = 0; p < 3; p++)
+            if (!planes[3 * i + p] || stride[p] < L.row_bytes[p])
+                return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
+    }
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
+        return rc;
+    hipStream_t saved = c->stream;
+    const size_t pfs[3] = {0, 0, 0};
+    for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        if (i >= 3) {
+            (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);   // planes of frame i-3 consumed
+            (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);   // floats of frame i-3 copied out
+        }
+        for (int p = 0; p < 3; p++)
+            if (hipMemcpy2DAsync(dp[p], stride[p], planes[3 * i + p], stride[p], L.row_bytes[p], L.rows[p],
+                                 hipMemcpyHostToDevice, c->s_h2d) != hipSuccess)
+                rc = fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.h2d, c->s_h2d);
+        (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+        c->stream = c->s_kern;
+        rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
+        c->stream = saved;
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.kern, c->s_kern);
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        if (hipMemcpyAsync(rgb_out[i], sl.d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h) != hipSuccess)
+            rc = fail(c, LUMAHIP_ERR_HIP, "D2H copy of frame %u failed", i);
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+    }
+    c->stream = saved;
+    HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+    HIPCHK(c, hipStreamSynchronize(c->s_kern));
+    HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+    return rc;
 }
 
 extern "C" int lumahip_transform_color_space_host(lumahip_ctx *c, float *frame, unsigned w, unsigned h, int toCs, float sc)

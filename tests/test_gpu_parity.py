@@ -360,3 +360,30 @@ def test_python_host_mirror_of_the_reference_interface(L, oracle_mod):
     ov = (q.getMapping()[:-1] * np.float32(1.5)).astype(np.float32)
     q2.setQuantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, mapping_override=ov)
     assert q2.getMapping()[-1] == q.getMapping()[-1] and q2.getMapping()[5] == ov[5]
+
+
+def test_pipelined_batch_host_entry_points(L, oracle_mod):
+    """lumahip_encode_frames_host / lumahip_decode_frames_host (3-slot pipeline over three streams) give exactly
+    the results of single-frame calls, for more frames than slots and with pinned and pageable buffers"""
+    o = oracle_mod
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    w, h, n = 320, 180, 8
+    frames = [o.synth_frame(w, h, frame=100 + i) for i in range(n)]
+    q.ctx.host_register(frames[0])
+    try:
+        planes, st, means = q.ctx.encode_frames(frames, 1.0, 2)
+    finally:
+        q.ctx.host_unregister(frames[0])
+    for i in range(n):
+        e, _, avg = orc.encode(frames[i].copy(), 1.0, 2)
+        assert all(np.array_equal(a, b) for a, b in zip(planes[i], e)), i
+        assert means[i] == pytest.approx(avg, rel=1e-3)
+    outs = q.ctx.decode_frames(planes, st, w, h, 1.0, 2)
+    for i in range(n):
+        assert same_bits(outs[i], orc.decode(planes[i], st, w, h, 1.0, 2)), i
+    # a second batch of a different size re-sizes the slots
+    f2 = [o.synth_frame(64, 32, frame=i) for i in range(4)]
+    p2, st2, _ = q.ctx.encode_frames(f2, 1.0, 3)
+    for i in range(4):
+        e, _, _ = orc.encode(f2[i].copy(), 1.0, 3)
+        assert all(np.array_equal(a, b) for a, b in zip(p2[i], e))

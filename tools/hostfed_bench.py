@@ -41,11 +41,28 @@ def main():
             fn()
         return (time.perf_counter() - t0) / n
 
+    nb = 12
+    fr = [f.copy() for _ in range(nb)]
+    outs = [np.empty_like(f) for _ in range(nb)]
+    pls = [[np.zeros((hs[p], st[p]), dtype=np.uint8) for p in range(3)] for _ in range(nb)]
+    fp = (C.c_void_p * nb)(*[a.ctypes.data for a in fr])
+    op = (C.c_void_p * nb)(*[a.ctypes.data for a in outs])
+    bp = (C.c_void_p * (3 * nb))(*[pl.ctypes.data for tri in pls for pl in tri])
+
+    def encb():
+        ctx._chk(ctx.L.lumahip_encode_frames_host(ctx.h, fp, nb, w, h, 1.0, 2, bp, ss, None))
+
+    def decb():
+        ctx._chk(ctx.L.lumahip_decode_frames_host(ctx.h, bp, ss, nb, w, h, 2, 1.0, op))
+
     for label in ("pageable", "pinned (lumahip_host_register)"):
         if label.startswith("pinned"):
-            for a in [f, out] + planes:
+            for a in [f, out] + planes + fr + outs + [pl for tri in pls for pl in tri]:
                 ctx.host_register(a)
         te, td = t(enc), t(dec)
+        tbe, tbd = t(encb, 3) / nb, t(decb, 3) / nb
+        print("%-32s pipelined batch of %d: encode %.2f ms/frame = %.0f Mpixel/s | decode %.2f ms/frame = %.0f Mpixel/s"
+              % (label, nb, tbe * 1e3, w * h / tbe / 1e6, tbd * 1e3, w * h / tbd / 1e6), flush=True)
         print("%-32s encode %.2f ms/frame = %.0f Mpixel/s (%.1f GB/s over PCIe) | decode %.2f ms/frame = %.0f Mpixel/s"
               % (label, te * 1e3, w * h / te / 1e6, 15.0 * w * h / te / 1e9, td * 1e3, w * h / td / 1e6), flush=True)
 
