@@ -77,6 +77,20 @@ LH_DEV float div_nr(float a, float b) { return div_nr_r(a, b, rcp_nr(b)); }
 // bit-identical except a = -0 (gives +0) and a = +-inf (gives NaN).  Licensed only where a > 0, finite
 // or NaN.  The same construction is NOT exact for 410, 224, 1.8814f, 1.4746f, 0.6780f (checked), so those
 // divisors keep div_ieee.
+// Same construction for divisor 219 (also verified exhaustively: exact except a = -0 and a = +-inf), and a
+// version of /255 whose licence is "a is finite and not -0" (e.g. the sum x + 128.0f, which is never -0).
+LH_DEV float div_219_fin(float a)
+{
+#ifdef LH_NO_FAST_DIV
+    return a / 219.0f;
+#else
+    const float rc = 1.0f / 219.0f;
+    const float q = a * rc;
+    const float r = __builtin_fmaf(-219.0f, q, a);
+    return __builtin_fmaf(r, rc, q);
+#endif
+}
+
 LH_DEV float div_255_pos(float a)
 {
 #ifdef LH_NO_FAST_DIV
@@ -120,18 +134,22 @@ LH_DEV float pq_decode(float val, const XformConst &k)
 }
 
 // the same two functions on the branch-free powf; `slow` is raised when any argument left its domain
+// Divisions on the short path (div_nr): licensed for the "regular" pixel only -- val in {0} u [1e-10, FLT_MAX],
+// Lmax in [1e-6, 1e9] (checked by the caller), Lp in [4e-3, 1.3e6], Vp in [0, 1.01] with c2 - c3*Vp in [0.02, 18.9]:
+// every operand, quotient and residual is a normal float (or an exact zero).  A NaN or inf anywhere ends up as a
+// NaN argument of powf_regular, which raises `slow`, and the pixel is redone with IEEE division throughout.
 LH_DEV float pq_encode_r(float val, const XformConst &k, bool &slow)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
-    const float Lp = powf_regular(div_ieee(val, k.Lmax), n, *k.pw, slow);
-    return powf_regular(div_ieee(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, slow);
+    const float Lp = powf_regular(div_nr(val, k.Lmax), n, *k.pw, slow);
+    return powf_regular(div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, slow);
 }
 
 LH_DEV float pq_decode_r(float val, const XformConst &k, bool &slow)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float Vp = powf_regular(val, 1.0f / m, *k.pw, slow);
-    return k.Lmax * powf_regular(div_ieee(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, slow);
+    return k.Lmax * powf_regular(div_nr(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, slow);
 }
 
 template <int CS>
@@ -213,10 +231,16 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
         B = pq_encode(std_max(b, 1e-10f), k);
     }
     const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
-    const float yv = div_ieee(219.0f * y + 16.0f, 255.0f);
-    c0 = REGULAR ? pq_decode_r(yv, k, slow) : pq_decode(yv, k);
-    c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
-    c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
+    if constexpr (REGULAR) {
+        // 219y+16 >= 16 and 224t+128 (never -0) are finite here; |B-y|, |R-y| <= ~2.1, zero or >= ~1e-13
+        c0 = pq_decode_r(div_255_pos(219.0f * y + 16.0f), k, slow);
+        c1 = div_255_pos(224.0f * div_nr(B - y, 1.8814f) + 128.0f);
+        c2 = div_255_pos(224.0f * div_nr(R - y, 1.4746f) + 128.0f);
+    } else {
+        c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
+        c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
+        c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
+    }
 }
 
 // Straight-line evaluation first; the (rare) pixel with a NaN / inf / denormal / out-of-range power argument
@@ -224,7 +248,7 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
 template <>
 LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    bool slow = false;
+    bool slow = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
     ycbcr_fwd<true>(r, g, b, k, c0, c1, c2, slow);
     if (__builtin_expect(slow, 0))
         ycbcr_fwd<false>(r, g, b, k, c0, c1, c2, slow);
@@ -245,11 +269,20 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 template <bool REGULAR>
 LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, bool &slow)
 {
-    float y = REGULAR ? pq_encode_r(c0, k, slow) : pq_encode(c0, k);
-    y = div_ieee(255.0f * y - 16.0f, 219.0f);
-    float blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
-    float red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
-    float green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
+    float y, blue, red, green;
+    if constexpr (REGULAR) {
+        // c0 is a table value in {0} u [1e-6, Lmax]; c1, c2 in [1e-10, ~260]: 255y-16 is finite and never -0,
+        // the other numerators are zero or of magnitude >= ~1e-8 and <= ~1e5
+        y = div_219_fin(255.0f * pq_encode_r(c0, k, slow) - 16.0f);
+        blue = y + div_nr(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
+        red = y + div_nr(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
+        green = div_nr((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
+    } else {
+        y = div_ieee(255.0f * pq_encode(c0, k) - 16.0f, 219.0f);
+        blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
+        red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
+        green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
+    }
     red = std_max(0.0f, std_min(1.0f, red));
     green = std_max(0.0f, std_min(1.0f, green));
     blue = std_max(0.0f, std_min(1.0f, blue));
@@ -267,7 +300,8 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
 template <>
 LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
 {
-    bool slow = false;
+    // out-of-range colour codes (c1, c2 > 1) or a non-finite table value leave the licensed ranges: slow path
+    bool slow = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f) || !(c1 <= 1.0f && c2 <= 1.0f && c0 <= 3.0e38f);
     ycbcr_inv<true>(c0, c1, c2, k, r, g, b, slow);
     if (__builtin_expect(slow, 0))
         ycbcr_inv<false>(c0, c1, c2, k, r, g, b, slow);
