@@ -387,3 +387,36 @@ def test_pipelined_batch_host_entry_points(L, oracle_mod):
     for i in range(4):
         e, _, _ = orc.encode(f2[i].copy(), 1.0, 3)
         assert all(np.array_equal(a, b) for a, b in zip(p2[i], e))
+
+
+@pytest.mark.parametrize("rgb,codes", [
+    ((1, 1, 1), (307, 81, 192)), ((100, 100, 100), (1040, 81, 192)), ((10000, 0, 0), (1707, 185, 214)),
+    ((0, 10000, 0), (1975, 51, 231)), ((0, 0, 10000), (1466, 72, 65)), ((0, 0, 0), (3, 86, 194)),
+    ((1e-6, 1e-6, 1e-6), (3, 86, 194)), ((0.5, 20, 3), (676, 53, 222)), ((-5, 2, 1), (229, 0, 164)),
+    ((np.nan, 1, 1), (2047, 255, 255)), ((np.inf, 1, 1), (2047, 86, 194)), ((65504, 65504, 65504), (2047, 81, 192)),
+])
+def test_survey_constant_colour_pins_on_gpu(L, rgb, codes):
+    """the known-answer codes SURVEY.md 8(c) recorded from the real reference encoder, straight through the C ABI"""
+    q = L.LumaQuantizer()
+    q.setQuantizer(*CONFIGS["pq11_luv8"])
+    f = np.empty((3, 2, 2), dtype=np.float32)
+    for c in range(3):
+        f[c] = np.float32(rgb[c])
+    planes, _, _ = q.ctx.encode_frame(f, 1.0, 2)
+    got = (int(planes[0].view("<u2")[0, 0]), int(planes[1].view("<u2")[0, 0]), int(planes[2].view("<u2")[0, 0]))
+    assert got == codes
+    assert np.all(planes[0].view("<u2")[:2, :2] == codes[0])
+
+
+@pytest.mark.parametrize("rgb,codes", [
+    ((1, 1, 1), (573, 514, 514)), ((0.5, 20, 3), (755, 470, 344)), ((0, 0, 0), (64, 514, 514)),
+    ((10000, 0, 0), (403, 329, 1023)), ((np.nan, 1, 1), (1023, 1023, 1023)),
+])
+def test_survey_ycbcr_pins_on_gpu(L, rgb, codes):
+    q = L.LumaQuantizer()
+    q.setQuantizer(*CONFIGS["pq10_ycbcr10"])
+    f = np.empty((3, 2, 2), dtype=np.float32)
+    for c in range(3):
+        f[c] = np.float32(rgb[c])
+    planes, _, _ = q.ctx.encode_frame(f, 20.0, 2)
+    assert (int(planes[0].view("<u2")[0, 0]), int(planes[1].view("<u2")[0, 0]), int(planes[2].view("<u2")[0, 0])) == codes

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Kernel time of ONE device-resident frame per launch (what a per-frame caller sees once data is on the GPU)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import lumahdrv_amd as L  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    for blk, pcu in ((256, 0), (256, 2), (256, 4), (512, 0), (512, 2), (1024, 1), (1024, 2)):
+        os.environ["LUMAHIP_BLOCK"] = str(blk)
+        os.environ["LUMAHIP_BLOCKS_PER_CU"] = str(pcu)
+        ctx = L.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11))
+        line = "block %4d wg/CU %d:" % (blk, pcu)
+        for (w, h) in ((1280, 720), (1920, 1080), (3840, 2160), (7680, 4320)):
+            n3 = 3 * w * h
+            nb = 24
+            _, hs, st, _ = L.plane_geometry(w, h, 2)
+            psz = [hs[p] * st[p] for p in range(3)]
+            src = torch.empty(nb * n3, dtype=torch.float32, device=dev)
+            planes = [torch.zeros(nb * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+            ctx.synth_frames_device(src.data_ptr(), n3, nb, w, h)
+            ms = []
+            for rep in range(3):
+                for b in range(nb):
+                    pl = [planes[p].data_ptr() + b * psz[p] for p in range(3)]
+                    ms.append(ctx.time_launches(0, 1, src.data_ptr() + b * n3 * 4, n3, 1, w, h, 1.0, 2, pl, st, psz))
+            m = sorted(ms)[len(ms) // 2]
+            line += "  %dx%d %.1f us (%.0f Gpx/s)" % (w, h, m * 1e3, w * h / m / 1e6)
+            del src, planes
+        print(line, flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()
