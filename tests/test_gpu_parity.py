@@ -420,3 +420,43 @@ def test_survey_ycbcr_pins_on_gpu(L, rgb, codes):
         f[c] = np.float32(rgb[c])
     planes, _, _ = q.ctx.encode_frame(f, 20.0, 2)
     assert (int(planes[0].view("<u2")[0, 0]), int(planes[1].view("<u2")[0, 0]), int(planes[2].view("<u2")[0, 0])) == codes
+
+
+@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+def test_kernels_write_only_inside_their_planes(L, oracle_mod, profile):
+    """guard bands around every device buffer and the stride padding of every row must come back untouched, for
+    sizes that leave partially filled tiles (the unit / tile grid overhangs the frame)"""
+    import torch
+    o = oracle_mod
+    cfg = CONFIGS["pq8_luv8"] if profile < 2 else CONFIGS["pq11_luv8"]
+    q, orc = pair(L, o, cfg)
+    dev = torch.device("cuda:0")
+    G = 4096
+    q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for (w, h, nf) in ((258, 10, 3), (64, 6, 2), (1284, 22, 1)):
+        n3 = 3 * w * h
+        _, hs, st, bps = L.plane_geometry(w, h, profile)
+        st = tuple(s + 16 for s in st)                      # extra stride padding that must stay untouched
+        ws = (w, w // 2 if profile in (0, 2) else w, w // 2 if profile in (0, 2) else w)
+        psz = [hs[p] * st[p] for p in range(3)]
+        frames = np.stack([o.synth_frame(w, h, frame=7 + i) for i in range(nf)])
+        src = torch.from_numpy(frames.reshape(-1)).to(dev)
+        bufs = [torch.full((G + nf * psz[p] + G,), 0xA5, dtype=torch.uint8, device=dev) for p in range(3)]
+        q.ctx.encode_frames_device(src.data_ptr(), n3, nf, w, h, 1.0, profile, [b.data_ptr() + G for b in bufs], st, psz)
+        torch.cuda.synchronize()
+        for p in range(3):
+            hb = bufs[p].cpu().numpy()
+            assert np.all(hb[:G] == 0xA5) and np.all(hb[-G:] == 0xA5), (w, h, p)
+            body = hb[G:-G].reshape(nf, hs[p], st[p])
+            assert np.all(body[:, :, ws[p] * bps:] == 0xA5), (w, h, p)
+            for i in range(nf):
+                e, _, _ = orc.encode(frames[i].copy(), 1.0, profile)
+                assert np.array_equal(body[i][:, :ws[p] * bps], e[p][:, :ws[p] * bps]), (w, h, p, i)
+        out = torch.full((G // 4 + nf * n3 + G // 4,), -777.0, dtype=torch.float32, device=dev)
+        q.ctx.decode_frames_device([b.data_ptr() + G for b in bufs], st, psz, nf, w, h, profile, 1.0,
+                                   out.data_ptr() + G, n3)
+        torch.cuda.synchronize()
+        ho = out.cpu().numpy()
+        assert np.all(ho[:G // 4] == -777.0) and np.all(ho[-(G // 4):] == -777.0)
+        assert np.all(np.isfinite(ho[G // 4:-(G // 4)]))
+    q.ctx.set_stream(None)
