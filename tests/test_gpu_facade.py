@@ -83,3 +83,38 @@ def test_simple_enc_dec_tools_end_to_end(oracle_mod, tmp_path):
         for i, n in enumerate("RGB"):
             exp = dec[i].astype(np.float16).astype(np.float32)
             assert np.array_equal(ch[n].view(np.uint32), exp.view(np.uint32)), n
+
+
+@pytest.mark.gpu
+def test_stream_metadata_matches_the_reference_attachments(oracle_mod, tmp_path):
+    """the raw plane stream written by LumaEncoder::initialize carries the reference's attachments 430..436 with
+    the reference's payloads (src/luma_encoder.cpp:78-104), including the quirk that the table attachment holds
+    getSize() = maxVal floats, one fewer than the table"""
+    import struct
+    o = oracle_mod
+    exe = build_facade_test(str(tmp_path))
+    stream = str(tmp_path / "m.lhs")
+    subprocess.run([exe, stream, "64", "32", "1", "2", "10", "2"], capture_output=True, text=True, check=True)
+    d = open(stream, "rb").read()
+    assert d[:8] == b"LHIPSTR1"
+    w, h, prof = struct.unpack_from("<III", d, 8)
+    natt = struct.unpack_from("<I", d, 24)[0]
+    assert (w, h, prof, natt) == (64, 32, 2, 7)
+    p = 28
+    att = {}
+    for _ in range(natt):
+        aid, dl = struct.unpack_from("<II", d, p)
+        p += 8 + dl
+        sz = struct.unpack_from("<I", d, p)[0]
+        att[aid] = d[p + 4:p + 4 + sz]
+        p += 4 + sz
+    assert sorted(att) == [430, 431, 432, 433, 434, 435, 436]
+    assert struct.unpack("<I", att[430])[0] == 10 and struct.unpack("<I", att[431])[0] == 8
+    assert struct.unpack("<i", att[432])[0] == o.PTF_PQ and struct.unpack("<i", att[433])[0] == o.CS_YCBCR
+    lut = o.Oracle(o.PTF_PQ, 10, o.CS_YCBCR, 8, 1e4, 0.005).mapping
+    assert len(att[434]) == 4 * (lut.size - 1)                       # getSize() floats, not getSize()+1
+    assert np.array_equal(np.frombuffer(att[434], dtype="<f4").view(np.uint32), lut[:-1].view(np.uint32))
+    assert struct.unpack("<f", att[435])[0] == 1.0
+    assert struct.unpack("<2f", att[436]) == (np.float32(1e4), np.float32(0.005))
+    frame_bytes = 64 * 32 * 2 + 2 * 32 * 16 * 2
+    assert len(d) - p == frame_bytes                                  # one frame of tight 4:2:0 16-bit planes
