@@ -240,6 +240,9 @@ class RefQuantizer:
             L.ref_quantize_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]
             L.ref_dequantize_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]
             L.ref_transform_color_space.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_float]
+            if hasattr(L, "ref_encode_frame"):
+                L.ref_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_int,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float)]
             RefQuantizer._L = L
         self.L = RefQuantizer._L
         self.h = self.L.ref_create()
@@ -280,6 +283,19 @@ class RefQuantizer:
         out = np.empty_like(a)
         self.L.ref_dequantize_array(self.h, a.ctypes.data, out.ctypes.data, a.size, ch)
         return out
+
+    def encode(self, frame: np.ndarray, sc=1.0, profile=2, align=32):
+        """the real LumaQuantizer (transformColorSpace + per-sample quantize) under the harness's restatement of
+        setVpxChannel's loop; mutates `frame`.  Returns (planes, strides, avg)."""
+        assert frame.dtype == np.float32 and frame.flags.c_contiguous and frame.shape[0] == 3
+        h, w = frame.shape[1:]
+        _, hs, strides, _ = plane_geometry(w, h, profile, align)
+        planes = [np.zeros((hs[p], strides[p]), dtype=np.uint8) for p in range(3)]
+        pp = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        st = (C.c_int * 3)(*strides)
+        avg = C.c_float(0)
+        self.L.ref_encode_frame(self.h, frame.ctypes.data, w, h, sc, profile, pp, st, C.byref(avg))
+        return planes, strides, float(avg.value)
 
     def transform(self, frame: np.ndarray, to_cs: bool, sc: float = 1.0) -> np.ndarray:
         assert frame.dtype == np.float32 and frame.flags.c_contiguous and frame.shape[0] == 3

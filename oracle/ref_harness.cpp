@@ -68,4 +68,46 @@ int ref_transform_color_space(void *q, float *buf, unsigned w, unsigned h, int t
     return ok ? 1 : 0;
 }
 
+/* Whole-frame encode for the bench's cpu_baseline ("kind": "reference"): the REAL
+ * LumaQuantizer::transformColorSpace and LumaQuantizer::quantize (one call per sample, as the reference makes
+ * them), driven by a restatement of the plane loop of LumaEncoder::setVpxChannel (src/luma_encoder.cpp:260-317),
+ * which itself cannot be compiled here (it needs libvpx / libebml / libmatroska headers).  Mutates `buf` like the
+ * reference does.  profile as in the reference: 0/2 = 4:2:0, 1/3 = 4:4:4; > 1 = 16-bit samples. */
+void ref_encode_frame(void *qv, float *buf, unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
+                      const int stride[3], float *avg_out)
+{
+    LumaQuantizer *q = static_cast<LumaQuantizer *>(qv);
+    ref_transform_color_space(qv, buf, w, h, 1, sc);
+    const bool sub = (profile == 0 || profile == 2);
+    const int m = profile > 1 ? 2 : 1;
+    for (int plane = 0; plane < 3; plane++) {
+        const float *src = buf + (size_t)plane * w * h;
+        unsigned char *out = planes[plane];
+        const int pw = (plane && sub) ? (int)((w + 1) >> 1) : (int)w, ph = (plane && sub) ? (int)((h + 1) >> 1) : (int)h;
+        float avg = 0.0f;
+        for (int y = 0; y < ph; y++)
+            for (int x = 0; x < pw; x++) {
+                float res;
+                if (plane && sub) {
+                    const size_t i1 = 2 * (size_t)x + 4 * (size_t)y * pw, i2 = i1 + 2 * (size_t)pw;
+                    res = 0.25f * (src[i1] + src[i1 + 1] + src[i2] + src[i2 + 1]);
+                } else {
+                    res = src[x + (size_t)y * pw];
+                    avg += res;
+                }
+                res = q->quantize(res, plane);
+                if (profile > 1) {
+                    unsigned char bl = res / 256;
+                    unsigned char bh = res - bl * 256;
+                    out[m * x + (size_t)y * stride[plane] + 1] = bl;
+                    out[m * x + (size_t)y * stride[plane]] = bh;
+                } else {
+                    out[m * x + (size_t)y * stride[plane]] = (unsigned char)(int)res;
+                }
+            }
+        if (plane == 0 && avg_out)
+            *avg_out = avg / (pw * ph);
+    }
+}
+
 } /* extern "C" */

@@ -110,3 +110,27 @@ def test_roundtrip_decode_of_encode(oracle_mod):
         Y = 0.212656 * src[0] + 0.715158 * src[1] + 0.072186 * src[2]
         Yd = 0.212656 * out[0] + 0.715158 * out[1] + 0.072186 * out[2]
         assert np.median(np.abs(np.log2(Yd / Y))) < (0.2 if profile < 2 else 0.02)
+
+
+def test_live_reference_whole_frame_encode(oracle_mod):
+    """the oracle's whole-frame encode against the REAL LumaQuantizer driven through the harness's plane loop
+    (oracle/ref_harness.cpp: ref_encode_frame), every profile; PSI/HDR-VDP included (tables compiled into the
+    reference).  Also reproduces the SURVEY Y-plane digest with the real quantizer."""
+    o = oracle_mod
+    if not o.have_ref():
+        pytest.skip("oracle/_ref/libluma_ref.so not built (needs /root/reference)")
+    for name, cfg in CONFIGS.items():
+        qq = o.Oracle(*cfg, table=table_for(o, cfg))
+        r = o.RefQuantizer(*cfg)
+        if not hasattr(r.L, "ref_encode_frame"):
+            pytest.skip("stale reference library")
+        f = o.synth_frame(96, 40, frame=2)
+        f[:, 0, :3] = [[np.nan, 0, -1], [1, 0, 5], [1, 0, 2]]
+        for profile in (0, 1, 2, 3):
+            a, _, avga = qq.encode(f.copy(), 1.0, profile)
+            b, _, avgb = r.encode(f.copy(), 1.0, profile)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, profile)
+            assert (np.isnan(avga) and np.isnan(avgb)) or avga == avgb
+    r = o.RefQuantizer(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    planes, _, _ = r.encode(o.test_frame(1280, 720), 1.0, 2)
+    assert o.survey_digest(o.packed_rows(planes[0], 2560)) == "e0ff09731298e8f6"
