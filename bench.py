@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--workload", default="pq11_luv", choices=["pq11_luv", "pq10_ycbcr", "log12_luv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="4K frames the CPU oracle encodes (bounded sample)")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes from the rocprofv3 PMC passes (tools/collect_traffic.py); optional")
     return ap.parse_args()
