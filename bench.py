@@ -70,6 +70,12 @@ WORKLOADS = {
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries (RCCL with NCCL_DEBUG=VERSION, the ROCm runtime) print
+    # banners to the C-level stdout, flushed at exit -- i.e. after anything Python prints.  So file descriptor 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,9 +83,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LUMAHIP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all_reduce) with one rank too
+    use_dist = world > 1 or os.environ.get("LUMAHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
     n_gpus = world
 
     import lumahdrv_amd as L   # after torch: one HIP runtime in the process
@@ -134,18 +143,18 @@ def main():
         for i in range(Wm):
             fn(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(K):
             fn(Wm + i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -248,8 +257,8 @@ def main():
             res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
     if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
