@@ -460,3 +460,35 @@ def test_kernels_write_only_inside_their_planes(L, oracle_mod, profile):
         assert np.all(ho[:G // 4] == -777.0) and np.all(ho[-(G // 4):] == -777.0)
         assert np.all(np.isfinite(ho[G // 4:-(G // 4)]))
     q.ctx.set_stream(None)
+
+
+def test_per_frame_statistics_exact_min_max(L, oracle_mod):
+    """the optional per-frame statistics of the encode kernel (wave64 reductions + float atomics): min and max of
+    transformed channel 0 are order-independent, so they must equal the oracle's exactly; the sum (the reference's
+    mean-luminance accumulator, src/luma_encoder.cpp:276,294,314) to float tolerance.  Several frames per launch,
+    tiles overhanging the frame."""
+    import torch
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    for name in ("pq11_luv8", "pq12_rgb", "pq10_ycbcr10"):
+        cfg = CONFIGS[name]
+        q, orc = pair(L, o, cfg)
+        q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        w, h, nf = 1284, 70, 5
+        n3 = 3 * w * h
+        frames = np.stack([o.synth_frame(w, h, frame=40 + i) * np.float32(1 + i) for i in range(nf)])
+        src = torch.from_numpy(frames.reshape(-1)).to(dev)
+        _, hs, st, _ = L.plane_geometry(w, h, 2)
+        psz = [hs[p] * st[p] for p in range(3)]
+        planes = [torch.zeros(nf * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        stats = torch.zeros(3 * nf, dtype=torch.float32, device=dev)
+        q.ctx.encode_frames_device(src.data_ptr(), n3, nf, w, h, 1.0, 2, [p.data_ptr() for p in planes], st, psz,
+                                   stats.data_ptr())
+        torch.cuda.synchronize()
+        s = stats.cpu().numpy().reshape(nf, 3)
+        for i in range(nf):
+            t = frames[i].copy()
+            orc.transform(t, True, 1.0)
+            assert s[i, 1] == t[0].min() and s[i, 2] == t[0].max(), (name, i)
+            assert s[i, 0] == pytest.approx(float(t[0].astype(np.float64).sum()), rel=1e-4)
+        q.ctx.set_stream(None)
