@@ -22,3 +22,16 @@ def oracle_mod():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """`make` is incremental: a no-op when __graft_entry__.build() already ran, a full build on a fresh clone, so
+    the suite does not depend on test order or on a prior build step.  (No GPU needed: hipcc cross-compiles.)"""
+    import shutil
+    if shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc"):
+        from lumahdrv_amd import capi
+        capi.build_library()
+    from oracle import oracle_py
+    oracle_py.build(ref=True)
+    yield
