@@ -204,6 +204,12 @@ def test_unaligned_strides_and_bad_arguments(L, oracle_mod):
         q.ctx.encode_frame(np.zeros((3, 5, 8), dtype=np.float32), 1.0, 2)
     with pytest.raises(L.LumaHipError):
         q.ctx.encode_frame(np.zeros((3, 4, 8), dtype=np.float32), 1.0, 7)
+    for empty in ((3, 0, 8), (3, 4, 0)):          # empty frames: "Invalid frame size" as well
+        with pytest.raises(L.LumaHipError):
+            q.ctx.encode_frame(np.zeros(empty, dtype=np.float32), 1.0, 2)
+    assert q.transformColorSpace(np.zeros((3, 0, 0), dtype=np.float32), True, 1.0) is True   # zero iterations, true
+    with pytest.raises(L.LumaHipError):           # no quantizer set yet
+        L.Context().encode_frame(np.ones((3, 2, 2), dtype=np.float32))
     bad = L.LumaQuantizer()
     bad.setQuantizer(L.PTF_PQ, 11, 9, 8, 1e4, 0.005)   # unknown colour space: transformColorSpace returns false
     assert bad.transformColorSpace(np.ones((3, 2, 2), dtype=np.float32), True, 1.0) is False
