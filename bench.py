@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="per-launch HBM bytes from the rocprofv3 PMC passes (tools/collect_traffic.py); optional")
+                    help="per-launch HBM bytes from the rocprofv3 PMC passes (tools/profile_round.sh + tools/summarize_profile.py); optional")
     return ap.parse_args()
 
 
