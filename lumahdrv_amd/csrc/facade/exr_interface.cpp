@@ -192,8 +192,23 @@ float ExrInterface::halfToFloat(uint16_t h)
 
 bool ExrInterface::testFrame(LumaFrame &frame, unsigned int w, unsigned int h) { return lumaTestFrame(frame, w, h); }
 
+static bool readFrameImpl(const char *inputFile, LumaFrame &frame);
+
 bool ExrInterface::readFrame(const char *inputFile, LumaFrame &frame)
 {
+    try {
+        return readFrameImpl(inputFile, frame);
+    } catch (const LumaException &) {
+        throw;
+    } catch (const std::exception &e) {  // bad_alloc, length_error ...: same conversion the reference applies
+        throw LumaException(e.what());
+    }
+}
+
+static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
+{
+    const int NO_COMPRESSION = ExrInterface::NO_COMPRESSION, RLE_COMPRESSION = ExrInterface::RLE_COMPRESSION,
+              ZIP_COMPRESSION = ExrInterface::ZIP_COMPRESSION;
     const Bytes data = slurp(inputFile);
     Reader rd(data);
     if (rd.i32() != 20000630)
@@ -280,6 +295,10 @@ bool ExrInterface::readFrame(const char *inputFile, LumaFrame &frame)
     default: throw LumaException("Reading of luminance only frames not yet supported");
     }
     (void)lineOrder;  // every chunk carries its own y, so the order of chunks in the file does not matter
+    // A corrupt header must not make us allocate gigabytes: every scan line needs a chunk in the file, and deflate
+    // expands at most ~1032:1, so the decoded pixel bytes are bounded by the file size.
+    if ((double)lineBytes * (double)H > 1040.0 * (double)data.size() + 65536.0)
+        throw LumaException("EXR: data window is inconsistent with the file size");
 
     frame.width = (unsigned int)W;
     frame.height = (unsigned int)H;
@@ -332,13 +351,13 @@ bool ExrInterface::readFrame(const char *inputFile, LumaFrame &frame)
                     } else if (typ[k] == 2) {
                         float f;
                         memcpy(&f, p + 4 * x, 4);
-                        hv = floatToHalf(f);  // Imf::Rgba holds halfs: FLOAT channels are narrowed on read
+                        hv = ExrInterface::floatToHalf(f);  // Imf::Rgba holds halfs: FLOAT channels are narrowed on read
                     } else {
                         uint32_t u;
                         memcpy(&u, p + 4 * x, 4);
-                        hv = floatToHalf((float)u);
+                        hv = ExrInterface::floatToHalf((float)u);
                     }
-                    dst[x] = halfToFloat(hv);
+                    dst[x] = ExrInterface::halfToFloat(hv);
                 }
             }
         }
