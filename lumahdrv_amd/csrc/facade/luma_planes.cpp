@@ -122,15 +122,17 @@ void LumaRawStreamReader::open(const char *file)
         !get_u32(m_f, prof) || fread(&m_fps, 4, 1, m_f) != 1 || !get_u32(m_f, natt))
         throw LumaException(std::string("'") + file + "' is not a Luma HIP plane stream");
     m_profile = (int)prof;
+    if (m_w == 0 || m_h == 0 || (m_w & 1) || (m_h & 1) || m_w > 65536 || m_h > 65536 || prof > 3 || natt > 1024)
+        throw LumaException(std::string("'") + file + "' has an implausible plane stream header");
     for (uint32_t i = 0; i < natt; i++) {
         LumaAttachment a;
         uint32_t dl = 0, sz = 0;
-        if (!get_u32(m_f, a.id) || !get_u32(m_f, dl))
+        if (!get_u32(m_f, a.id) || !get_u32(m_f, dl) || dl > 4096)
             throw LumaException("truncated attachment table");
         a.description.resize(dl);
         if (dl && fread(&a.description[0], 1, dl, m_f) != dl)
             throw LumaException("truncated attachment table");
-        if (!get_u32(m_f, sz))
+        if (!get_u32(m_f, sz) || sz > (64u << 20))
             throw LumaException("truncated attachment table");
         a.data.resize(sz);
         if (sz && fread(a.data.data(), 1, sz, m_f) != sz)
