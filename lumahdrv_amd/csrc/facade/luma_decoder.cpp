@@ -34,6 +34,9 @@ bool LumaDecoder::initialize(const char *inputFile, bool verbose)
     const float *mapping = NULL;
     bool have430 = false, have431 = false, have432 = false, have433 = false;
     for (unsigned int idx = 0; m_source->getAttachment(idx, &buffer, id, size); idx++) {
+        const unsigned int need = (id == 436) ? 8u : (id == 434 ? 0u : 4u);
+        if (id >= 430 && id <= 436 && size < need)
+            throw LumaException("Malformed Luma HDRv meta data (attachment too short)");
         switch (id) {
         case 430: memcpy(&m_params.ptfBitDepth, buffer, sizeof(unsigned int)); have430 = true; break;
         case 431: memcpy(&m_params.colorBitDepth, buffer, sizeof(unsigned int)); have431 = true; break;
