@@ -186,6 +186,11 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
                           unsigned char *const planes_dev[3], const int stride[3],
                           const size_t plane_frame_stride[3], float *avg_ms);
 
+/* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
+ * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the
+ * device function with the host libm exhaustively. */
+int lumahip_powf_probe_device(lumahip_ctx *ctx, float *out_dev, uint32_t first_bits, size_t n, float y, int regular);
+
 /* Pin caller-owned host memory (hipHostRegister) so that the _host entry points DMA it at PCIe rate instead
  * of going through the runtime's pageable staging path.  Optional; unregister before freeing the memory. */
 int lumahip_host_register(lumahip_ctx *ctx, void *host_ptr, size_t bytes);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
-    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
     L.lumahip_synth_frames_device.argtypes = [vp, vp, sz, u, u, u, C.c_uint64, C.c_uint64]
     L.lumahip_time_launches.argtypes = [vp, i, i, vp, sz, u, u, u, f, i, pp3, ip3, sp3, C.POINTER(f)]
     L.lumahip_probe_encode_traffic_device.argtypes = [vp, vp, sz, u, u, u, pp3, ip3, sp3, i, C.POINTER(f)]
+    L.lumahip_powf_probe_device.argtypes = [vp, vp, C.c_uint32, sz, f, i]
     L.lumahip_host_register.argtypes = [vp, vp, sz]
     L.lumahip_host_unregister.argtypes = [vp, vp]
     L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
@@ -338,6 +339,9 @@ class Context:
                                                              _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
                                                              _arr3(C.c_size_t, plane_frame_strides), iters, C.byref(ms)))
         return float(ms.value)
+
+    def powf_probe_device(self, out_ptr, first_bits, n, y, regular=True):
+        self._chk(self.L.lumahip_powf_probe_device(self.h, out_ptr, first_bits, n, y, int(bool(regular))))
 
     def host_register(self, arr: np.ndarray):
         """pin a numpy array's memory for PCIe-rate transfers by the host entry points"""

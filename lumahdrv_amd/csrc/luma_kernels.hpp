@@ -797,6 +797,34 @@ __global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
     }
 }
 
+// ---- powf probe: out[i] = powf_glibc(bits-to-float(first + i), y) (tests: device powf == host libm, exhaustively)
+__global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_bits, size_t n, float y, int regular)
+{
+    __shared__ PowfTables s_pw;
+    const double lt[16][2] = LH_POWF_LOG2_TAB;
+    const uint64_t et[32] = LH_POWF_EXP2_TAB;
+    if (threadIdx.x < 16) {
+        s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
+        s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
+    }
+    if (threadIdx.x < 32)
+        s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first_bits + (uint32_t)i);
+        float r;
+        if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
+            bool slow = false;
+            r = powf_regular(x, y, s_pw, slow);
+            if (slow)
+                r = powf_glibc(x, y, s_pw);
+        } else {
+            r = powf_glibc(x, y, s_pw);
+        }
+        out[i] = r;
+    }
+}
+
 // ---- synthetic frames --------------------------------------------------------------
 LH_DEV uint64_t splitmix64(uint64_t x)
 {

@@ -1117,6 +1117,19 @@ extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *co
 
 // ---------------------------------------------------------------------------------------- memory helpers
 
+extern "C" int lumahip_powf_probe_device(lumahip_ctx *c, float *out_dev, uint32_t first_bits, size_t n, float y, int regular)
+{
+    if (!c || !out_dev || n == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 16)
+        grid = (long)c->num_cu * 16;
+    hipLaunchKernelGGL(k_powf_probe, dim3((unsigned)grid), dim3(256), 0, c->stream, out_dev, first_bits, n, y, regular);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
 extern "C" int lumahip_host_register(lumahip_ctx *c, void *p, size_t bytes)
 {
     if (!c || !p || !bytes)

@@ -500,6 +500,61 @@ void lo_decode_frame_mt(const lo_quantizer *q, const unsigned char *const planes
     run_bands(&j, nthreads, NULL);
 }
 
+/* ---------------------------------------------------------------- libm powf sweep (checker for the device powf) */
+
+typedef struct {
+    const float *got;
+    uint32_t first;
+    size_t i0, i1;
+    float y;
+    size_t bad;
+    uint32_t first_bad;
+} powf_job;
+
+static void *powf_main(void *arg)
+{
+    powf_job *j = (powf_job *)arg;
+    size_t i;
+    for (i = j->i0; i < j->i1; i++) {
+        uint32_t b = j->first + (uint32_t)i, g, e;
+        float x, r;
+        memcpy(&x, &b, 4);
+        r = powf(x, j->y);
+        memcpy(&g, &j->got[i], 4);
+        memcpy(&e, &r, 4);
+        if (g != e && !(r != r && j->got[i] != j->got[i])) {
+            if (!j->bad)
+                j->first_bad = b;
+            j->bad++;
+        }
+    }
+    return NULL;
+}
+
+/* compares got[i] with libm powf(bits(first+i), y) for i in [0,n); returns the number of mismatches (NaN == NaN) */
+size_t lo_powf_compare(const float *got, uint32_t first, size_t n, float y, int nthreads, uint32_t *first_bad)
+{
+    pthread_t th[256];
+    powf_job jobs[256];
+    size_t bad = 0;
+    int t;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    for (t = 0; t < nthreads; t++) {
+        jobs[t].got = got; jobs[t].first = first; jobs[t].y = y; jobs[t].bad = 0; jobs[t].first_bad = 0;
+        jobs[t].i0 = n * (size_t)t / nthreads;
+        jobs[t].i1 = n * (size_t)(t + 1) / nthreads;
+        pthread_create(&th[t], NULL, powf_main, &jobs[t]);
+    }
+    for (t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].bad && !bad && first_bad)
+            *first_bad = jobs[t].first_bad;
+        bad += jobs[t].bad;
+    }
+    return bad;
+}
+
 /* ---------------------------------------------------------------- input generators and digests */
 
 void lo_test_frame(float *buf, unsigned w_, unsigned h_)

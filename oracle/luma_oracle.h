@@ -89,6 +89,10 @@ void lo_encode_frame_mt(const lo_quantizer *q, float *frame, unsigned w, unsigne
 void lo_decode_frame_mt(const lo_quantizer *q, const unsigned char *const planes[3], const int stride[3],
                         unsigned w, unsigned h, int profile, float sc, float *frame, int nthreads);
 
+/* Checker for the device powf: compares got[i] with this host's libm powf(float-with-bits(first+i), y), threaded.
+ * (The reference calls libm powf, src/luma_quantizer.cpp:485-501.) */
+size_t lo_powf_compare(const float *got, uint32_t first, size_t n, float y, int nthreads, uint32_t *first_bad);
+
 /* ExrInterface::testFrame pattern, src/exr_interface.cpp:50-70 */
 void lo_test_frame(float *buf, unsigned w, unsigned h);
 

@@ -71,6 +71,8 @@ def lib():
         L.lo_decode_frame.argtypes = [C.POINTER(_Q), pp, ip, C.c_uint, C.c_uint, C.c_int, C.c_float, C.c_void_p]
         L.lo_encode_frame_mt.argtypes = L.lo_encode_frame.argtypes + [C.c_int]
         L.lo_decode_frame_mt.argtypes = L.lo_decode_frame.argtypes + [C.c_int]
+        L.lo_powf_compare.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
+        L.lo_powf_compare.restype = C.c_size_t
         L.lo_test_frame.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
         L.lo_splitmix64.argtypes = [C.c_uint64]
         L.lo_splitmix64.restype = C.c_uint64
@@ -191,6 +193,14 @@ class Oracle:
         else:
             self.L.lo_decode_frame(C.byref(self.q), pp, st, w, h, profile, sc, out.ctypes.data)
         return out
+
+
+def powf_compare(got: np.ndarray, first_bits: int, y: float, threads: int = 0):
+    """(#mismatches, first mismatching bit pattern) of got[i] vs this host's libm powf(bits(first+i), y)"""
+    got = np.ascontiguousarray(got, dtype=np.float32)
+    fb = C.c_uint32(0)
+    n = lib().lo_powf_compare(got.ctypes.data, first_bits, got.size, y, threads or (os.cpu_count() or 1), C.byref(fb))
+    return int(n), int(fb.value)
 
 
 def test_frame(w=1280, h=720) -> np.ndarray:

@@ -92,3 +92,35 @@ def test_device_powf_matches_host_libm_dense_sweep(oracle_mod):
     assert q.transformColorSpace(c, False, 20.0)
     orc.transform(d, False, 20.0)
     assert ((c.view(np.uint32) == d.view(np.uint32)) | (np.isnan(c) & np.isnan(d))).all()
+
+
+@pytest.mark.parametrize("regular", [True, False])
+def test_device_powf_equals_host_libm_for_every_nonnegative_float(oracle_mod, regular):
+    """pow_glibc.hpp on the GPU vs this host's libm powf, bit for bit, for EVERY non-negative fp32 (0, denormals,
+    normals, +inf, the NaNs up to 0x7fffffff) and every 257th negative pattern, for each of the four exponents of
+    LumaQuantizer::transformPQ (src/luma_quantizer.cpp:485-501) -- 4 x 2.15e9 arguments.  `regular` = the branch-free
+    form + fallback that the kernels actually execute."""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    m, n_ = np.float32(78.8438), np.float32(0.1593)
+    ys = [float(n_), float(m), float(np.float32(1.0) / m), float(np.float32(1.0) / n_)]
+    n = 1 << 27
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    total_bad = 0
+    for y in ys:
+        for chunk in range(16):                      # 16 x 2^27 = every pattern 0 .. 0x7fffffff
+            ctx.powf_probe_device(out.data_ptr(), chunk * n, n, y, regular)
+            bad, fb = o.powf_compare(out.cpu().numpy(), chunk * n, y)
+            assert bad == 0, ("y=%r first mismatch at bits 0x%08x" % (y, fb))
+            total_bad += bad
+    # negative half, sampled: a chunk starting at every 2^27 boundary, 2^20 patterns each
+    for y in ys:
+        for chunk in range(16, 32):
+            ctx.powf_probe_device(out.data_ptr(), chunk * n, 1 << 20, y, regular)
+            bad, fb = o.powf_compare(out[:1 << 20].cpu().numpy(), chunk * n, y)
+            assert bad == 0, ("y=%r first mismatch at bits 0x%08x" % (y, fb))
+    assert total_bad == 0
