@@ -86,10 +86,10 @@ int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, fl
 
 /* Host-only (no GPU, no context): the search index lumahip_set_quantizer would build for `lut`.
  * info[0] = mode (as in lumahip_quantizer_info), info[1] = right shift applied to the fp32 bit pattern,
- * info[2] = key of bucket 0, info[3] = refinement steps; start_out (nullable, start_cap entries) receives the
- * per-bucket byte offsets (4 x first candidate index); the number of buckets is what lumahip_quantizer_info
- * reports -- pass start_cap >= 8192. */
-int lumahip_lut_index_host(const float *lut, size_t n, int info[4], uint16_t *start_out, size_t start_cap);
+ * info[2] = key of bucket 0, info[3] = refinement steps, info[4] = number of buckets (the last one is the "above
+ * the whole table" bucket whose entry is maxVal); start_out (nullable, start_cap entries, pass >= 8192) receives
+ * the per-bucket byte offsets (4 x first candidate index). */
+int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *start_out, size_t start_cap);
 
 /* introspection of the search index built for the current LUT (tests):
  * info[0] = mode (0 = literal bisection, LUT in LDS; 1 = bucketed search, LUT in LDS;

@@ -140,12 +140,12 @@ def build_lut(ptf: int, bitdepth: int, max_lum: float = 1e4, min_lum: float = 0.
 def lut_index(lut: np.ndarray):
     """host-only: (mode, shift, kmin, steps, start[]) of the bucketed search index for a table (no GPU needed)"""
     lut = np.ascontiguousarray(lut, dtype=np.float32)
-    info = (C.c_int * 4)()
+    info = (C.c_int * 5)()
     start = np.zeros(8192, dtype=np.uint16)
     rc = lib().lumahip_lut_index_host(lut.ctypes.data, lut.size, info, start.ctypes.data, start.size)
     if rc != OK:
         raise LumaHipError(rc, "lumahip_lut_index_host failed")
-    return dict(mode=info[0], shift=info[1], kmin=info[2], steps=info[3], start=start)
+    return dict(mode=info[0], shift=info[1], kmin=info[2], steps=info[3], nbuckets=info[4], start=start[:info[4]].copy())
 
 
 def _arr3(ctype, vals):

@@ -194,7 +194,7 @@ LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, f
     const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
     const float rd = rcp_nr(den);
     // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410: div_255_pos is exact
-    c0 = Y;
+    c0 = any_nan ? __builtin_nanf("") : Y;  // sign-clear NaN for the table search (POSNAN); a NaN either way
     c1 = div_255_pos(div_nr_r(4.0f * x, den, rd) * 410.f);
     c2 = div_255_pos(div_nr_r(9.0f * y, den, rd) * 410.f);
 }
@@ -459,23 +459,35 @@ LH_DEV float lds_f32(const float *lut, int byte_off)
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut) + byte_off);
 }
 
-template <int N, int STEPS, typename LutPtr, typename BucketPtr>
+// signed median of three (lo <= hi): clamp in one VALU op
+LH_DEV int med3_i32(int x, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));  // one SGPR per VOP3 (constant bus)
+    return r;
+}
+
+// POSNAN: the caller guarantees that a NaN among v[] has its sign bit clear (then its key exceeds every finite
+// key and the top bucket, whose entry is maxVal, yields the reference's answer without a separate NaN test).
+template <int N, int STEPS, bool POSNAN, typename LutPtr, typename BucketPtr>
 LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
 {
     int l4[N];
     const int maxVal4 = q.maxVal * 4;
+    // the table has nbuckets entries for keys kmin .. kmin+nbuckets-1 (the last one is the "above everything"
+    // bucket = maxVal); index it with the clamped raw key through a pre-biased base
+    const auto biased = bucket - q.kmin;
+    const int khi = q.kmin + q.nbuckets - 1;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        int k = (__float_as_int(v[i]) >> q.shift) - q.kmin;
-        k = min(max(k, 0), q.nbuckets - 1);
-        l4[i] = bucket[k];
-    }
+    for (int i = 0; i < N; i++)
+        l4[i] = biased[med3_i32(__float_as_int(v[i]) >> q.shift, q.kmin, khi)];
     if constexpr (STEPS == 1) {
         // one refinement probe: fetch map[l], map[l+1], map[l+2] at once and select
         float a[N], b[N], c[N];
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
+            if constexpr (!POSNAN)
+                l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
             a[i] = lds_f32(lut, l4[i]);
             b[i] = lds_f32(lut, l4[i] + 4);
             c[i] = lds_f32(lut, l4[i] + 8);
@@ -515,7 +527,7 @@ LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut,
         float ml[N], mr[N];
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
+            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];  // (probes may have moved a +NaN's l4 nowhere: keep the test)
             ml[i] = lds_f32(lut, l4[i]);
             mr[i] = lds_f32(lut, l4[i] + 4);
         }
@@ -530,15 +542,15 @@ LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut,
 
 // MODE: 0 literal bisection (LDS), 2 literal bisection (global), 1 bucketed with run-time step count,
 //       11 / 12 bucketed with 1 / 2 compile-time steps
-template <int MODE, int N, typename LutPtr, typename BucketPtr>
+template <int MODE, int N, bool POSNAN = false, typename LutPtr, typename BucketPtr>
 LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
 {
     if constexpr (MODE == 1) {
-        quantize_lut_bucket<N, -1>(v, code, lut, bucket, q);
+        quantize_lut_bucket<N, -1, POSNAN>(v, code, lut, bucket, q);
     } else if constexpr (MODE == 11) {
-        quantize_lut_bucket<N, 1>(v, code, lut, bucket, q);
+        quantize_lut_bucket<N, 1, POSNAN>(v, code, lut, bucket, q);
     } else if constexpr (MODE == 12) {
-        quantize_lut_bucket<N, 2>(v, code, lut, bucket, q);
+        quantize_lut_bucket<N, 2, POSNAN>(v, code, lut, bucket, q);
     } else {
 #pragma unroll
         for (int i = 0; i < N; i++)

@@ -342,7 +342,7 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
 #pragma unroll
             for (int i = 0; i < VW; i++)
                 v[i] = c0[r * VW + i];
-            quantize_lut<LM, VW>(v, row, lut, s_bucket, a.q);
+            quantize_lut<LM, VW, CS == CS_LUV>(v, row, lut, s_bucket, a.q);  // Lu'v': Y is positive or a sign-clear NaN
             store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
         }
     }
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
         if (!a.lut_channel)
             c[0] = quantize_color(v[0], a.q.maxC);
         else if (a.q.mode == 1)
-            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);  // run-time step count
+            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);  // run-time step count, any NaN sign
         else if (a.q.mode == 0)
             quantize_lut<0, 1>(v, c, s_lut, s_bucket, a.q);
         else

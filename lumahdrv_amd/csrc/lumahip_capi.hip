@@ -251,7 +251,7 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
 }
 
 // host-only view of the search index (no GPU, no context): what lumahip_set_quantizer would build for this table
-extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[4], uint16_t *start_out, size_t start_cap)
+extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *start_out, size_t start_cap)
 {
     if (!lut || !info || n < 2 || n > 65536)
         return LUMAHIP_ERR_ARG;
@@ -260,6 +260,7 @@ extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[4], u
     info[1] = ix.shift;
     info[2] = ix.kmin;
     info[3] = ix.steps;
+    info[4] = ix.nbuckets;
     if (start_out) {
         if (start_cap < ix.start.size())
             return LUMAHIP_ERR_ARG;

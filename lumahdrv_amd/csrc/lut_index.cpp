@@ -59,9 +59,12 @@ LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth)
         const int shift = 23 - B;
         const int kmin = fbits(lut[lo]) >> shift, kmax = fbits(lut[maxVal]) >> shift;
         const int K = kmax - kmin + 1;
-        if (K > 8192)
+        if (K + 1 > 8192)
             break;
-        std::vector<uint16_t> start(K);
+        std::vector<uint16_t> start(K + 1);
+        // one bucket past the table's last key: every value there is > map[maxVal] (and +inf / sign-clear NaNs land
+        // there too); starting the search AT maxVal gives the reference's answer maxVal directly
+        start[K] = (uint16_t)(4 * maxVal);
         int maxspan = 0;
         for (int k = 0; k < K; k++) {
             // bucket 0 also receives every value below it (key clamp), the last bucket every value above
@@ -78,7 +81,7 @@ LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth)
             best.mant_bits = B;
             best.shift = shift;
             best.kmin = kmin;
-            best.nbuckets = K;
+            best.nbuckets = K + 1;
             best.steps = S;
             best.pad = (1 << S) + 1;
             best.start = std::move(start);

@@ -87,9 +87,9 @@ def test_lut_search_index_is_sound(L, golden_dir):
                             np.exp(rng.uniform(np.log(1e-7), np.log(1e6), 200000)).astype(np.float32),
                             np.array([0.0, -1.0, 1e-45, 3e38, np.inf, -np.inf], dtype=np.float32)])
         bits = v.view(np.int32).astype(np.int64)
-        nb = int(np.count_nonzero(ix["start"])) + 1            # buckets are non-decreasing; bucket 0 starts at 0
-        k = np.clip((bits >> ix["shift"]) - ix["kmin"], 0, None)
-        k = np.minimum(k, (int(m.view(np.int32)[maxVal]) >> ix["shift"]) - ix["kmin"])
+        nb = ix["nbuckets"]
+        assert ix["start"][nb - 1] == 4 * maxVal               # the "above the whole table" bucket
+        k = np.clip((bits >> ix["shift"]) - ix["kmin"], 0, nb - 1)   # the device's v_med3_i32 on the raw key
         l = ix["start"][k].astype(np.int64) // 4
         mp = np.concatenate([m, np.full(2 ** ix["steps"] + 1, np.nan, dtype=np.float32)])
         for s in range(ix["steps"] - 1, -1, -1):
