@@ -91,11 +91,20 @@ int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, fl
  * the per-bucket byte offsets (4 x first candidate index). */
 int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *start_out, size_t start_cap);
 
+/* Host-only (no GPU, no context): the threshold records lumahip_set_quantizer builds for a monotone finite table
+ * (lumahdrv_amd/csrc/lut_index.hpp): quantize(v) = (rec[clamp(bits(v) >> shift, kmin, kmin+nbuckets-1) - kmin]
+ * + (bits(v) & (2^shift - 1))) >> shift for every float that is not a sign-set NaN (those give maxVal).
+ * info = {ok, mantissa bits of the key, shift, kmin, nbuckets}; ok = 0 when the table does not qualify (NaNs,
+ * decreasing or duplicate entries, too many records) and the kernels run the literal bisection instead.
+ * rec_out (nullable, rec_cap entries) receives the records. */
+int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
+
 /* introspection of the search index built for the current LUT (tests):
- * info[0] = mode (0 = literal bisection, LUT in LDS; 1 = bucketed search, LUT in LDS;
- *                 2 = literal bisection, LUT read from global memory (bitdepth > 12)),
+ * info[0] = mode (0 = literal bisection, LUT in LDS; 1 = two-level bucketed search (LUMAHIP_SEARCH=bucket only);
+ *                 2 = literal bisection, LUT read from global memory (bitdepth > 12);
+ *                 3 = threshold records in LDS; 4 = threshold records in global memory),
  * info[1] = mantissa bits of the bucket key, info[2] = number of buckets, info[3] = refinement steps,
- * info[4] = LDS bytes per workgroup */
+ * info[4] = LDS bytes per workgroup of the encode-side kernels */
 int lumahip_quantizer_info(const lumahip_ctx *ctx, int info[5]);
 
 /* ---- host entry points (drop-in: H2D, kernel, D2H, synchronous) -------------------------------- */
@@ -185,6 +194,12 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
                           unsigned nframes, unsigned w, unsigned h, float sc, int profile,
                           unsigned char *const planes_dev[3], const int stride[3],
                           const size_t plane_frame_stride[3], float *avg_ms);
+
+/* Test probe: the luminance search exactly as the encode kernels instantiate it (four values per thread, the
+ * context's search mode; posnan != 0 selects the Lu'v' kernels' variant, which relies on NaNs being sign-clear)
+ * over the n consecutive fp32 bit patterns first_bits, first_bits+1, ...: out_dev[i] = code.  n % 4 == 0.
+ * Counterpart of LumaQuantizer::quantize(val, 0) (src/luma_quantizer.cpp:222-235). */
+int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int posnan);
 
 /* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
  * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the

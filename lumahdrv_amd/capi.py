@@ -19,12 +19,12 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_lut_index_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_lut_index_host", "lumahip_thresh_index_host", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
-    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_quantize_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
     L.lumahip_lut_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
+    L.lumahip_thresh_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
@@ -106,6 +107,7 @@ def lib():
     L.lumahip_time_launches.argtypes = [vp, i, i, vp, sz, u, u, u, f, i, pp3, ip3, sp3, C.POINTER(f)]
     L.lumahip_probe_encode_traffic_device.argtypes = [vp, vp, sz, u, u, u, pp3, ip3, sp3, i, C.POINTER(f)]
     L.lumahip_powf_probe_device.argtypes = [vp, vp, C.c_uint32, sz, f, i]
+    L.lumahip_quantize_probe_device.argtypes = [vp, vp, C.c_uint32, sz, i]
     L.lumahip_host_register.argtypes = [vp, vp, sz]
     L.lumahip_host_unregister.argtypes = [vp, vp]
     L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
@@ -146,6 +148,31 @@ def lut_index(lut: np.ndarray):
     if rc != OK:
         raise LumaHipError(rc, "lumahip_lut_index_host failed")
     return dict(mode=info[0], shift=info[1], kmin=info[2], steps=info[3], nbuckets=info[4], start=start[:info[4]].copy())
+
+
+def thresh_index(lut: np.ndarray):
+    """host-only: the threshold records of a table (include/lumahip.h lumahip_thresh_index_host); no GPU needed"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    info = (C.c_int * 5)()
+    rc = lib().lumahip_thresh_index_host(lut.ctypes.data, lut.size, info, None, 0)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_thresh_index_host failed")
+    d = dict(ok=bool(info[0]), mant_bits=info[1], shift=info[2], kmin=info[3], nbuckets=info[4], rec=None)
+    if d["ok"]:
+        rec = np.zeros(info[4], dtype=np.uint32)
+        rc = lib().lumahip_thresh_index_host(lut.ctypes.data, lut.size, info, rec.ctypes.data, rec.size)
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_thresh_index_host failed")
+        d["rec"] = rec
+    return d
+
+
+def thresh_lookup(ix, v: np.ndarray) -> np.ndarray:
+    """numpy evaluation of the record table exactly as the kernels do it (sign-set NaNs excluded by the caller)"""
+    b = np.ascontiguousarray(v, dtype=np.float32).view(np.int32)
+    k = np.clip(b >> ix["shift"], ix["kmin"], ix["kmin"] + ix["nbuckets"] - 1) - ix["kmin"]
+    low = b.view(np.uint32) & np.uint32((1 << ix["shift"]) - 1)
+    return ((ix["rec"][k] + low) >> np.uint32(ix["shift"])).astype(np.int64)
 
 
 def _arr3(ctype, vals):
@@ -342,6 +369,10 @@ class Context:
 
     def powf_probe_device(self, out_ptr, first_bits, n, y, regular=True):
         self._chk(self.L.lumahip_powf_probe_device(self.h, out_ptr, first_bits, n, y, int(bool(regular))))
+
+    def quantize_probe_device(self, out_ptr, first_bits, n, posnan=False):
+        """uint16 codes of the n consecutive fp32 bit patterns from first_bits, through quantize_lut<mode, 4, posnan>"""
+        self._chk(self.L.lumahip_quantize_probe_device(self.h, out_ptr, first_bits, n, int(bool(posnan))))
 
     def host_register(self, arr: np.ndarray):
         """pin a numpy array's memory for PCIe-rate transfers by the host entry points"""

@@ -388,6 +388,7 @@ LH_DEVS void xform_inv<CS_RGB>(float c0, float c1, float c2, const XformConst &k
 struct QuantDev {
     const float *lut;        // global: maxVal+1 floats followed by `pad` NaNs
     const uint16_t *bucket;  // global: nbuckets bucket starts (mode 1)
+    const uint32_t *rec;     // global: nbuckets threshold records (modes 3, 4; lut_index.hpp)
     int lut_len;             // maxVal + 1
     int pad;
     int maxVal;
@@ -540,12 +541,38 @@ LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut,
     }
 }
 
+// Threshold records (lut_index.hpp, "Threshold records"): code = (rec[clamped key] + low bits of v) >> shift --
+// one 4-byte gather, no table probes, no subtractions; equal to the reference's bisection + nearest-of-two for
+// every float by construction of the records (host) and by the exhaustive sweep of tests/test_gpu_exhaustive.py.
+// `rec` points at the record of key kmin (LDS copy or global).  POSNAN: see quantize_lut_bucket.
+template <int N, bool POSNAN, typename RecPtr>
+LH_DEV void quantize_thresh(const float (&v)[N], int (&code)[N], RecPtr rec, const QuantDev &q)
+{
+    const auto biased = rec - q.kmin;
+    const int khi = q.kmin + q.nbuckets - 1;
+    const uint32_t lowmask = (1u << q.shift) - 1u;  // shift <= 23
+    uint32_t r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        r[i] = biased[med3_i32(__float_as_int(v[i]) >> q.shift, q.kmin, khi)];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int c = (int)((r[i] + (__float_as_uint(v[i]) & lowmask)) >> q.shift);
+        if constexpr (POSNAN)
+            code[i] = c;
+        else
+            code[i] = (v[i] != v[i]) ? q.maxVal : c;  // a sign-set NaN's key clamps to the bottom bucket
+    }
+}
+
 // MODE: 0 literal bisection (LDS), 2 literal bisection (global), 1 bucketed with run-time step count,
-//       11 / 12 bucketed with 1 / 2 compile-time steps
+//       11 / 12 bucketed with 1 / 2 compile-time steps, 3 / 4 threshold records (LDS / global; `bucket` = records)
 template <int MODE, int N, bool POSNAN = false, typename LutPtr, typename BucketPtr>
 LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
 {
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 3 || MODE == 4) {
+        quantize_thresh<N, POSNAN>(v, code, bucket, q);
+    } else if constexpr (MODE == 1) {
         quantize_lut_bucket<N, -1, POSNAN>(v, code, lut, bucket, q);
     } else if constexpr (MODE == 11) {
         quantize_lut_bucket<N, 1, POSNAN>(v, code, lut, bucket, q);

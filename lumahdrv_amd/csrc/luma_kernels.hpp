@@ -69,16 +69,20 @@ struct DecArgs {
     int do_tmo, ldr_sim;
 };
 
-// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][bucket: nbuckets u16, rounded to 16 B][powf tables]
+// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][bucket: nbuckets u16 | records: nbuckets u32, rounded to
+// 16 B][powf tables].  Which parts a kernel stages is a compile-time set.
+enum : int { STAGE_LUT = 1, STAGE_BUCKET = 2, STAGE_REC = 4, STAGE_POWF = 8 };
+
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
 LH_DEV int lds_bucket_bytes(const QuantDev &q) { return (q.nbuckets * 2 + 15) & ~15; }
+LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
 
-template <bool NEED_BUCKET>
-LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, bool lut_in_lds, bool need_pw)
+template <int WHAT>
+LH_DEV int stage_tables(unsigned char *smem, const QuantDev &q)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     int off = 0;
-    if (lut_in_lds) {
+    if constexpr (WHAT & STAGE_LUT) {
         // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
         const int n4 = lds_lut_bytes(q) / 16;
         const float4 *g = reinterpret_cast<const float4 *>(q.lut);
@@ -86,16 +90,24 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, bool lut_in_lds
         for (int i = tid; i < n4; i += nt)
             s[i] = g[i];
         off += lds_lut_bytes(q);
-        if (NEED_BUCKET && q.mode == 1) {
-            const int b4 = lds_bucket_bytes(q) / 16;
-            const uint4 *gb = reinterpret_cast<const uint4 *>(q.bucket);
-            uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
-            for (int i = tid; i < b4; i += nt)
-                sb[i] = gb[i];
-            off += lds_bucket_bytes(q);
-        }
     }
-    if (need_pw) {
+    if constexpr (WHAT & STAGE_BUCKET) {
+        const int b4 = lds_bucket_bytes(q) / 16;
+        const uint4 *gb = reinterpret_cast<const uint4 *>(q.bucket);
+        uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
+        for (int i = tid; i < b4; i += nt)
+            sb[i] = gb[i];
+        off += lds_bucket_bytes(q);
+    }
+    if constexpr (WHAT & STAGE_REC) {
+        const int b4 = lds_rec_bytes(q) / 16;  // the device buffer is padded to 16 B
+        const uint4 *gb = reinterpret_cast<const uint4 *>(q.rec);
+        uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
+        for (int i = tid; i < b4; i += nt)
+            sb[i] = gb[i];
+        off += lds_rec_bytes(q);
+    }
+    if constexpr (WHAT & STAGE_POWF) {
         PowfTables *t = reinterpret_cast<PowfTables *>(smem + off);
         const double lt[16][2] = LH_POWF_LOG2_TAB;
         const uint64_t et[32] = LH_POWF_EXP2_TAB;
@@ -107,6 +119,7 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, bool lut_in_lds
             t->exp2_tab[tid] = et[tid];
     }
     __syncthreads();
+    return off;  // offset of the powf tables
 }
 
 // ---- sample stores / loads ------------------------------------------------------------------------
@@ -324,9 +337,9 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
 }
 
 // quantize + subsample + pack + store one transformed unit
-template <int CS, bool SUB, int VW, int LM, typename LutPtr>
+template <int CS, bool SUB, int VW, int LM, typename LutPtr, typename IdxPtr>
 LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const float (&c1)[2 * VW],
-                     const float (&c2)[2 * VW], const EncArgs &a, LutPtr lut, const uint16_t *s_bucket)
+                     const float (&c2)[2 * VW], const EncArgs &a, LutPtr lut, IdxPtr s_bucket)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
     const float maxC = a.q.maxC;
@@ -404,15 +417,15 @@ template <int CS, bool SUB, int VW, int LM>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool LUT_LDS = (LM != 2);
+    constexpr bool LUT_LDS = (LM == 0 || LM == 1 || LM == 11 || LM == 12);
     constexpr bool BUCKETED = (LM == 1 || LM == 11 || LM == 12);
-    stage_tables<true>(smem, a.q, LUT_LDS, CS == CS_YCBCR);
+    constexpr int WHAT = (LUT_LDS ? STAGE_LUT : 0) | (BUCKETED ? STAGE_BUCKET : 0) | (LM == 3 ? STAGE_REC : 0) |
+                         (CS == CS_YCBCR ? STAGE_POWF : 0);
+    const int pw_off = stage_tables<WHAT>(smem, a.q);
 
     const float *s_lut = reinterpret_cast<const float *>(smem);
     const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
-    int pw_off = 0;
-    if (LUT_LDS)
-        pw_off = lds_lut_bytes(a.q) + (BUCKETED ? lds_bucket_bytes(a.q) : 0);
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);  // LM == 3: the records are all there is
     XformConst k;
     k.sc = a.sc;
     k.Lmax = a.q.Lmax;
@@ -449,7 +462,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
             enc_transform<CS, VW>(u, a, k, c0, c1, c2, st);
         enc_load<VW>(u, a, t + G, tx, ty, NW, cs);
         if (valid) {
-            if constexpr (LUT_LDS)
+            if constexpr (LM == 3)
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
+            else if constexpr (LM == 4)
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, a.q.rec);
+            else if constexpr (LUT_LDS)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_bucket);
             else
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_bucket);
@@ -665,12 +682,12 @@ template <int CS, bool SUB, int VW, bool GL, bool DISP = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    stage_tables<false>(smem, a.q, !GL, CS == CS_YCBCR);
+    const int pw_off = stage_tables<(GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0)>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
     XformConst k;
     k.sc = a.sc;
     k.Lmax = a.q.Lmax;
-    k.pw = reinterpret_cast<const PowfTables *>(smem + (GL ? 0 : lds_lut_bytes(a.q)));
+    k.pw = reinterpret_cast<const PowfTables *>(smem + pw_off);
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -755,25 +772,64 @@ struct QArrArgs {
     int lut_channel;  // 1: LUT path, 0: colour path
 };
 
+// MODE: the table's search mode (lut_index.hpp LutMode), a template parameter so that each instantiation stages
+// exactly what it probes
+template <int MODE>
 __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const bool lds = a.q.mode != 2;
-    stage_tables<true>(smem, a.q, lds, false);
+    constexpr int WHAT = (MODE == 0 || MODE == 1) ? (STAGE_LUT | (MODE == 1 ? STAGE_BUCKET : 0)) : (MODE == 3 ? STAGE_REC : 0);
+    stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
     const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const float v[1] = {a.in[i]};
         int c[1];
         if (!a.lut_channel)
             c[0] = quantize_color(v[0], a.q.maxC);
-        else if (a.q.mode == 1)
+        else if constexpr (MODE == 3)
+            quantize_lut<3, 1>(v, c, s_lut, s_rec, a.q);     // any NaN sign
+        else if constexpr (MODE == 4)
+            quantize_lut<4, 1>(v, c, a.q.lut, a.q.rec, a.q);
+        else if constexpr (MODE == 1)
             quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);  // run-time step count, any NaN sign
-        else if (a.q.mode == 0)
+        else if constexpr (MODE == 0)
             quantize_lut<0, 1>(v, c, s_lut, s_bucket, a.q);
         else
             quantize_lut<2, 1>(v, c, a.q.lut, s_bucket, a.q);
         a.out[i] = (float)c[0];
+    }
+}
+
+// Test probe: quantize_lut<LM, 4, POSNAN> -- the instantiation the Lu'v' encode kernels call for a row of four
+// luminances -- over consecutive fp32 bit patterns (tests/test_gpu_exhaustive.py; POSNAN promises that a NaN has
+// its sign bit clear, so the sweep covers 0 .. 0x7fffffff).
+template <int LM, bool POSNAN>
+__global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16_t *out, uint32_t first_bits, size_t n4)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool LUT_LDS = (LM == 0 || LM == 1 || LM == 11 || LM == 12);
+    constexpr bool BUCKETED = (LM == 1 || LM == 11 || LM == 12);
+    stage_tables<(LUT_LDS ? STAGE_LUT : 0) | (BUCKETED ? STAGE_BUCKET : 0) | (LM == 3 ? STAGE_REC : 0)>(smem, q);
+    const float *s_lut = reinterpret_cast<const float *>(smem);
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(q));
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float v[4];
+        int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = __uint_as_float(first_bits + (uint32_t)(4 * i + j));
+        if constexpr (LM == 3)
+            quantize_lut<LM, 4, POSNAN>(v, c, s_lut, s_rec, q);
+        else if constexpr (LM == 4)
+            quantize_lut<LM, 4, POSNAN>(v, c, q.lut, q.rec, q);
+        else if constexpr (LUT_LDS)
+            quantize_lut<LM, 4, POSNAN>(v, c, s_lut, s_bucket, q);
+        else
+            quantize_lut<LM, 4, POSNAN>(v, c, q.lut, s_bucket, q);
+        store_samples<4>(reinterpret_cast<unsigned char *>(out + 4 * i), c, 2, 1);
     }
 }
 

@@ -17,6 +17,8 @@
 
 using namespace lh;
 
+static constexpr size_t LUMAHIP_REC_LDS_MAX = 72 * 1024;
+
 struct lumahip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -29,8 +31,11 @@ struct lumahip_ctx {
     unsigned bitdepth = 0, bitdepthC = 0;
     QuantDev q{};
     LutIndex idx;
+    ThreshIndex tix;
     float *d_lut = nullptr;
     uint16_t *d_bucket = nullptr;
+    uint32_t *d_rec = nullptr;
+    bool lut_in_lds = true;  // decode side: tables up to 12 bits are staged in LDS
     float minLum = 0.0f;
 
     // staging for the _host entry points
@@ -56,6 +61,7 @@ struct lumahip_ctx {
 
     int cs_override = -1;  // CS_PACK / CS_RGB while a pack-only / unpack-only call is in flight
     int block_threads = 256;
+    bool block_forced = false;
     int blocks_per_cu = 0;  // 0 = occupancy query
 };
 
@@ -121,8 +127,10 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
         c->num_cu = prop.multiProcessorCount;
     if (const char *e = getenv("LUMAHIP_BLOCK")) {
         int v = atoi(e);
-        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024)
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
             c->block_threads = v;
+            c->block_forced = true;
+        }
     }
     if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
         c->blocks_per_cu = atoi(e);
@@ -138,6 +146,7 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_bucket);
+    (void)hipFree(c->d_rec);
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
@@ -204,41 +213,72 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
-    c->idx = build_lut_index(lut, (int)n);
-    if (getenv("LUMAHIP_FORCE_LITERAL") && c->idx.mode == LUT_BUCKET_LDS) {
-        // test hook: run the reference's bisection literally even though the table qualifies for the bucketed
-        // search (tests/test_gpu_exhaustive.py compares the two over every fp32 bit pattern)
-        c->idx = LutIndex();
-        c->idx.mode = LUT_LITERAL_LDS;
+    // Search index.  Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit
+    // LUMAHIP_REC_LDS_MAX (two 1024-thread workgroups per CU then still fit the 160 KiB), else in global memory
+    // (L2-resident).  Anything else (NaNs, decreasing or duplicate entries -- a decoder
+    // may be handed any attachment-434 table) runs the reference's bisection literally.  Environment hooks for the
+    // tests and for A/B measurements: LUMAHIP_FORCE_LITERAL, LUMAHIP_SEARCH=bucket (the round-1 two-level search).
+    const char *search_env = getenv("LUMAHIP_SEARCH");
+    const bool want_bucket = search_env && !strcmp(search_env, "bucket");
+    c->tix = ThreshIndex();
+    c->idx = LutIndex();
+    c->lut_in_lds = (n <= 4096);
+    int mode = c->lut_in_lds ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
+    if (!getenv("LUMAHIP_FORCE_LITERAL")) {
+        if (want_bucket) {
+            c->idx = build_lut_index(lut, (int)n);
+            mode = c->idx.mode;
+        } else {
+            c->tix = build_thresh_index(lut, (int)n, 1 << 19);
+            if (c->tix.ok)
+                mode = (c->tix.rec.size() * 4 <= LUMAHIP_REC_LDS_MAX) ? LUT_THRESH_LDS : LUT_THRESH_GLOBAL;
+        }
     }
+    c->idx.mode = mode;
     const LutIndex &ix = c->idx;
     const size_t lut_floats = ((n + std::max(ix.pad, 1)) + 3) & ~(size_t)3;
     std::vector<float> padded(lut_floats, __builtin_nanf(""));
     memcpy(padded.data(), lut, n * sizeof(float));
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_bucket);
+    (void)hipFree(c->d_rec);
     c->d_lut = nullptr;
     c->d_bucket = nullptr;
+    c->d_rec = nullptr;
     HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
-    const size_t nb = ((size_t)ix.nbuckets + 7) & ~(size_t)7;
+    const size_t nb = mode == LUT_BUCKET_LDS ? (((size_t)ix.nbuckets + 7) & ~(size_t)7) : 0;
     if (nb) {
         std::vector<uint16_t> b(nb, 0);
         memcpy(b.data(), ix.start.data(), ix.nbuckets * sizeof(uint16_t));
         HIPCHK(c, hipMalloc(&c->d_bucket, nb * sizeof(uint16_t)));
         HIPCHK(c, hipMemcpy(c->d_bucket, b.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    if (c->tix.ok) {
+        std::vector<uint32_t> r((c->tix.rec.size() + 3) & ~(size_t)3, 0u);
+        memcpy(r.data(), c->tix.rec.data(), c->tix.rec.size() * sizeof(uint32_t));
+        HIPCHK(c, hipMalloc(&c->d_rec, r.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_rec, r.data(), r.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     QuantDev &q = c->q;
     q.lut = c->d_lut;
     q.bucket = c->d_bucket;
+    q.rec = c->d_rec;
     q.lut_len = (int)n;
     q.pad = (int)(lut_floats - n);
     q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
-    q.mode = ix.mode;
-    q.shift = ix.shift;
-    q.kmin = ix.kmin;
-    q.nbuckets = ix.nbuckets;
-    q.steps = ix.steps;
+    q.mode = mode;
+    if (c->tix.ok) {
+        q.shift = c->tix.shift;
+        q.kmin = c->tix.kmin;
+        q.nbuckets = c->tix.nbuckets;
+        q.steps = 0;
+    } else {
+        q.shift = ix.shift;
+        q.kmin = ix.kmin;
+        q.nbuckets = ix.nbuckets;
+        q.steps = ix.steps;
+    }
     q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);        // src/luma_quantizer.cpp:183
     q.cs = cs;
     q.Lmax = maxLum;
@@ -269,19 +309,59 @@ extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[5], u
     return (int)ix.start.size() >= 0 ? LUMAHIP_OK : LUMAHIP_ERR_ARG;
 }
 
-static size_t lds_bytes(const lumahip_ctx *c, bool need_bucket)
+// host-only view of the threshold records (no GPU, no context): info = {ok, mant_bits, shift, kmin, nbuckets}
+extern "C" int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap)
+{
+    if (!lut || !info || n < 2 || n > 65536)
+        return LUMAHIP_ERR_ARG;
+    const ThreshIndex ix = build_thresh_index(lut, (int)n, 1 << 19);
+    info[0] = ix.ok ? 1 : 0;
+    info[1] = ix.mant_bits;
+    info[2] = ix.shift;
+    info[3] = ix.kmin;
+    info[4] = ix.nbuckets;
+    if (rec_out && ix.ok) {
+        if (rec_cap < ix.rec.size())
+            return LUMAHIP_ERR_ARG;
+        memcpy(rec_out, ix.rec.data(), ix.rec.size() * sizeof(uint32_t));
+    }
+    return LUMAHIP_OK;
+}
+
+// dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)
+static size_t lds_bytes(const lumahip_ctx *c, bool encode_side)
 {
     const QuantDev &q = c->q;
     size_t b = 0;
-    if (q.mode != LUT_LITERAL_GLOBAL) {
-        b += ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
-        if (need_bucket && q.mode == LUT_BUCKET_LDS)
+    const size_t lut_b = ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
+    if (encode_side) {
+        if (q.mode == LUT_LITERAL_LDS || q.mode == LUT_BUCKET_LDS)
+            b += lut_b;
+        if (q.mode == LUT_BUCKET_LDS)
             b += ((size_t)q.nbuckets * 2 + 15) & ~(size_t)15;
+        if (q.mode == LUT_THRESH_LDS)
+            b += ((size_t)q.nbuckets * 4 + 15) & ~(size_t)15;
+    } else if (c->lut_in_lds) {
+        b += lut_b;
     }
     const int cs_eff = c->cs_override >= 0 ? c->cs_override : q.cs;
     if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTables);
     return b;
+}
+
+// Workgroup size of the fused kernels: 256 threads unless LUMAHIP_BLOCK says otherwise; search tables beyond
+// 32 KiB per workgroup would leave too few waves per CU at that size (160 KiB of LDS per CU), so the workgroup
+// grows with the table.
+static int block_threads_for(const lumahip_ctx *c, size_t lds)
+{
+    if (c->block_forced)
+        return c->block_threads;
+    if (lds > 53 * 1024)
+        return 1024;
+    if (lds > 32 * 1024)
+        return 512;
+    return c->block_threads;
 }
 
 extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
@@ -290,10 +370,10 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
         return LUMAHIP_ERR_ARG;
     if (!c->have_quant)
         return LUMAHIP_ERR_STATE;
-    info[0] = c->idx.mode;
-    info[1] = c->idx.mant_bits;
-    info[2] = c->idx.nbuckets;
-    info[3] = c->idx.steps;
+    info[0] = c->q.mode;
+    info[1] = c->tix.ok ? c->tix.mant_bits : c->idx.mant_bits;
+    info[2] = c->q.nbuckets;
+    info[3] = c->q.steps;
     info[4] = (int)lds_bytes(c, true);
     return LUMAHIP_OK;
 }
@@ -306,6 +386,10 @@ typedef void (*dec_kernel_t)(const DecArgs);
 template <int CS, bool SUB>
 static enc_kernel_t pick_enc2(int vw, int mode, int steps)
 {
+    if (mode == LUT_THRESH_LDS)
+        return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
+    if (mode == LUT_THRESH_GLOBAL)
+        return vw == 4 ? k_encode<CS, SUB, 4, 4> : k_encode<CS, SUB, 2, 4>;
     if (mode == LUT_BUCKET_LDS) {
         if (vw == 4 && steps == 1)
             return k_encode<CS, SUB, 4, 11>;
@@ -424,12 +508,14 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
     const int mode = c->q.mode;
-    int vw = (mode == LUT_BUCKET_LDS && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
+    const bool fast_search = (mode == LUT_BUCKET_LDS || mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
+    int vw = (fast_search && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
     EncArgs a{};
     a.q = c->q;
-    const int threads = c->block_threads;
+    const size_t lds = lds_bytes(c, true);
+    const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     a.src = rgb;
@@ -451,7 +537,6 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
     enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode, c->q.steps);
-    const size_t lds = lds_bytes(c, true);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles);
@@ -482,7 +567,7 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     HIPCHK(c, hipSetDevice(c->device));
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
-    const bool gl = (c->q.mode == LUT_LITERAL_GLOBAL);
+    const bool gl = !c->lut_in_lds;
     int vw = (!gl && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
@@ -490,7 +575,8 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
         return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
     DecArgs a{};
     a.q = c->q;
-    const int threads = c->block_threads;
+    const size_t lds = lds_bytes(c, false);
+    const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     a.dst = rgb;
@@ -518,7 +604,6 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
-    const size_t lds = lds_bytes(c, false);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles);
@@ -1060,13 +1145,21 @@ static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t 
     if (grid > (long)c->num_cu * 8)
         grid = (long)c->num_cu * 8;
     if (quant) {
-        size_t lds = 0;
-        if (c->q.mode != LUT_LITERAL_GLOBAL) {
-            lds = ((size_t)(c->q.lut_len + c->q.pad) * 4 + 15) & ~(size_t)15;
-            if (c->q.mode == LUT_BUCKET_LDS)
-                lds += ((size_t)c->q.nbuckets * 2 + 15) & ~(size_t)15;
+        const int cs_saved = c->cs_override;
+        c->cs_override = CS_PACK;  // no powf tables for the array kernels
+        const size_t lds = lds_bytes(c, true);
+        c->cs_override = cs_saved;
+        void (*kern)(const QArrArgs) = k_quantize_array<2>;
+        switch (c->q.mode) {
+        case LUT_LITERAL_LDS: kern = k_quantize_array<0>; break;
+        case LUT_BUCKET_LDS: kern = k_quantize_array<1>; break;
+        case LUT_THRESH_LDS: kern = k_quantize_array<3>; break;
+        case LUT_THRESH_GLOBAL: kern = k_quantize_array<4>; break;
+        default: break;
         }
-        hipLaunchKernelGGL(k_quantize_array, dim3((unsigned)grid), dim3(256), lds, c->stream, a);
+        if (lds > 64 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, c->stream, a);
     } else {
         hipLaunchKernelGGL(k_dequantize_array, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
     }
@@ -1127,6 +1220,44 @@ extern "C" int lumahip_powf_probe_device(lumahip_ctx *c, float *out_dev, uint32_
     if (grid > (long)c->num_cu * 16)
         grid = (long)c->num_cu * 16;
     hipLaunchKernelGGL(k_powf_probe, dim3((unsigned)grid), dim3(256), 0, c->stream, out_dev, first_bits, n, y, regular);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, uint32_t first_bits, size_t n, int posnan)
+{
+    if (!c || !out_dev || n == 0 || (n % 4) != 0 || !is_aligned(out_dev, 8))
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument (n must be a multiple of 4, out 8-byte aligned)");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int cs_saved = c->cs_override;
+    c->cs_override = CS_PACK;
+    const size_t lds = lds_bytes(c, true);
+    c->cs_override = cs_saved;
+    void (*kern)(const QuantDev, uint16_t *, uint32_t, size_t) = nullptr;
+    switch (c->q.mode) {
+    case LUT_LITERAL_LDS: kern = posnan ? k_quantize_probe<0, true> : k_quantize_probe<0, false>; break;
+    case LUT_LITERAL_GLOBAL: kern = posnan ? k_quantize_probe<2, true> : k_quantize_probe<2, false>; break;
+    case LUT_BUCKET_LDS:
+        if (c->q.steps == 1)
+            kern = posnan ? k_quantize_probe<11, true> : k_quantize_probe<11, false>;
+        else if (c->q.steps == 2)
+            kern = posnan ? k_quantize_probe<12, true> : k_quantize_probe<12, false>;
+        else
+            kern = posnan ? k_quantize_probe<1, true> : k_quantize_probe<1, false>;
+        break;
+    case LUT_THRESH_LDS: kern = posnan ? k_quantize_probe<3, true> : k_quantize_probe<3, false>; break;
+    case LUT_THRESH_GLOBAL: kern = posnan ? k_quantize_probe<4, true> : k_quantize_probe<4, false>; break;
+    }
+    if (!kern)
+        return fail(c, LUMAHIP_ERR_STATE, "unknown search mode %d", c->q.mode);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long grid = (long)((n / 4 + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, c->stream, c->q, out_dev, first_bits, n / 4);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }

@@ -23,7 +23,9 @@ namespace lh {
 enum LutMode : int {
     LUT_LITERAL_LDS = 0,    // reference bisection, table staged in LDS
     LUT_BUCKET_LDS = 1,     // bucketed search, table + bucket starts staged in LDS
-    LUT_LITERAL_GLOBAL = 2  // reference bisection on the table in global memory (bitdepth > 12)
+    LUT_LITERAL_GLOBAL = 2, // reference bisection on the table in global memory (bitdepth > 12)
+    LUT_THRESH_LDS = 3,     // threshold records (below), staged in LDS: ONE 4-byte LDS read per value
+    LUT_THRESH_GLOBAL = 4   // threshold records in global memory / L2 (record table too large for LDS)
 };
 
 struct LutIndex {
@@ -36,6 +38,42 @@ struct LutIndex {
     int pad = 1;        // NaN floats appended after the table: probes reach index maxVal + 2^S
     std::vector<uint16_t> start;  // K entries: BYTE offset (4 * first candidate index) per bucket
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Threshold records (the search the shipped kernels run for every monotone table).
+//
+// For a non-decreasing, NaN-free, finite table the reference's quantize(v) -- bisection, then "nearest of two" by
+// the two rounded subtractions (v - map[l]) < (map[r] - v) -- is a NON-DECREASING step function of v:
+//   * l(v) = clamp(#{entries <= v} - 1, 0, maxVal-1) is non-decreasing;
+//   * inside one interval, fl(v - map[l]) is non-decreasing and fl(map[r] - v) non-increasing in v (rounding is
+//     monotone), so once the comparison is false it stays false: the code switches from l to l+1 exactly once.
+// Hence quantize(v) = c0 + #{c : T[c] <= v} for thresholds T[c0+1] <= ... <= T[maxVal], T[c] = the smallest float
+// whose code is >= c.  The T[c] are found on the host by bisection over fp32 bit patterns with the reference's
+// loop evaluated LITERALLY (quantize_literal_host), so rounding ties and the table's irregularities are baked in.
+//
+// Record table: key = bits(v) >> shift (exponent + B mantissa bits), clamped to [kmin, kmin+nbuckets-1]; B is the
+// smallest value for which no key holds two thresholds.  rec[key-kmin] = (start << shift) | u with
+//   start = code of the first float of the bucket,  u = 0 (no threshold inside) or 2^shift - low(T) (one inside),
+// so that          code(v) = (rec[key] + (bits(v) & (2^shift - 1))) >> shift
+// -- the carry out of the low field is the "v >= T" test.  Bucket kmin (start c0, u 0) also receives everything
+// below it through the key clamp (negatives, -0, -inf: all code c0); the last bucket (start maxVal, u 0) receives
+// everything above the last threshold, +inf and sign-clear NaNs (the reference returns maxVal for any NaN; a
+// caller that may see a sign-set NaN tests for NaN explicitly).  tests/test_gpu_exhaustive.py compares this with
+// the literal bisection for all 2^32 bit patterns through the encode kernels themselves.
+struct ThreshIndex {
+    bool ok = false;
+    int mant_bits = 0;  // B
+    int shift = 0;      // 23 - B
+    int kmin = 0;
+    int nbuckets = 0;
+    std::vector<uint32_t> rec;
+};
+
+// the reference's loop, literally (src/luma_quantizer.cpp:222-235)
+int quantize_literal_host(float v, const float *lut, int maxVal);
+// device-equivalent evaluation of a record table (v must not be a sign-set NaN)
+int thresh_lookup_host(const ThreshIndex &ix, float v);
+ThreshIndex build_thresh_index(const float *lut, int n, int max_buckets);
 
 // lut has n = maxVal+1 entries
 LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth = 12);

@@ -1,12 +1,17 @@
 """Exhaustive statements that only a GPU makes affordable.
 
-1. The bucketed table search (lut_index.hpp / quantize_lut_bucket) returns the same code as the reference's
-   bisection + nearest-of-two for EVERY fp32 bit pattern (all 2^32: zeros, denormals, negatives, +-inf, every
-   NaN payload), for each shipped transfer function.  Both sides run on the GPU (LUMAHIP_FORCE_LITERAL selects
-   the literal kernel); the literal kernel itself is pinned against the oracle / the reference fixtures in
-   test_gpu_parity.py and spot-checked here against the oracle.
-2. The device powf (pow_glibc.hpp) equals the host libm powf on a dense sweep for the four PQ exponents
-   (the full 2^31 sweep per exponent is tools/verify_powf.cpp, host-side).
+1. The luminance search the kernels ship with -- threshold records, lut_index.hpp / quantize_thresh -- returns the
+   same code as the reference's bisection + nearest-of-two (src/luma_quantizer.cpp:222-235) for EVERY fp32 bit
+   pattern (all 2^32: zeros, denormals, negatives, +-inf, every NaN payload), for each shipped transfer function,
+   through three different instantiations:
+     a. the array kernel k_quantize_array (public LumaQuantizer::quantize over arrays; N = 1, explicit NaN test);
+     b. the ENCODE KERNEL ITSELF, k_encode<CS_RGB, 4:4:4, VW=4, records> (profile 3; RGB hands raw floats to the
+        search for all three planes; N = 4 and N = 8 call shapes, explicit NaN test);
+     c. quantize_lut<records, 4, POSNAN=true>, the instantiation the Lu'v' encode kernels call (they promise the
+        search a sign-clear NaN), over 0 .. 0x7fffffff = every non-negative float, +inf and every sign-clear NaN.
+   The other side of each comparison is the literal bisection kernel on the GPU (LUMAHIP_FORCE_LITERAL), itself
+   pinned against the oracle / the reference fixtures in test_gpu_parity.py and spot-checked here against the oracle.
+2. The device powf (pow_glibc.hpp) equals the host libm powf for every non-negative float, for the four PQ exponents.
 """
 import os
 
@@ -15,25 +20,43 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12)]
 
-@pytest.mark.parametrize("ptf,bits", [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12)])
-def test_bucketed_search_equals_bisection_for_every_float(oracle_mod, ptf, bits):
+
+def _pair(L, ptf, bits, cs):
+    """(records context, literal context) for the same table"""
+    lut = L.build_lut(ptf, bits, 1e4, 0.005)
+    os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
+    os.environ.pop("LUMAHIP_SEARCH", None)
+    fast = L.Context(0)
+    fast.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
+    assert fast.quantizer_info()["mode"] in (3, 4)
+    os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
+    try:
+        lit = L.Context(0)
+        lit.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
+    finally:
+        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
+    assert lit.quantizer_info()["mode"] in (0, 2)
+    return fast, lit
+
+
+def _oracle_for(o, ptf, bits, cs):
+    tab = None
+    if ptf in (0, 3):
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lumahdrv_amd", "data")
+        tab = np.fromfile(os.path.join(d, "ptf_%s_%d.f32" % ("psi" if ptf == 0 else "jnd_hdrvdp", bits)), dtype="<f4")
+    return o.Oracle(ptf, bits, cs, 8, 1e4, 0.005, table=tab)
+
+
+@pytest.mark.parametrize("ptf,bits", TABLES)
+def test_record_search_equals_bisection_for_every_float(oracle_mod, ptf, bits):
+    """(a): k_quantize_array, all 2^32 bit patterns"""
     import torch
     import lumahdrv_amd as L
     o = oracle_mod
     dev = torch.device("cuda:0")
-    lut = L.build_lut(ptf, bits, 1e4, 0.005)
-    os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
-    fast = L.Context(0)
-    fast.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
-    assert fast.quantizer_info()["mode"] == 1
-    os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
-    try:
-        lit = L.Context(0)
-        lit.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
-    finally:
-        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
-    assert lit.quantizer_info()["mode"] == 0
+    fast, lit = _pair(L, ptf, bits, L.CS_LUV)
     s = torch.cuda.current_stream().cuda_stream
     fast.set_stream(s)
     lit.set_stream(s)
@@ -41,6 +64,7 @@ def test_bucketed_search_equals_bisection_for_every_float(oracle_mod, ptf, bits)
     a = torch.empty(n, dtype=torch.float32, device=dev)
     b = torch.empty(n, dtype=torch.float32, device=dev)
     base = torch.arange(n, dtype=torch.int64, device=dev)
+    orc = _oracle_for(o, ptf, bits, o.CS_LUV)
     bad = 0
     for chunk in range(32):
         bits32 = (base + chunk * n).to(torch.int32) if chunk < 16 else (base + chunk * n - (1 << 32)).to(torch.int32)
@@ -52,13 +76,129 @@ def test_bucketed_search_equals_bisection_for_every_float(oracle_mod, ptf, bits)
             idx = torch.arange(0, n, 65537, device=dev)
             xs = x[idx].cpu().numpy()
             got = b[idx].cpu().numpy()
-            tab = None
-            if ptf in (0, 3):
-                d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lumahdrv_amd", "data")
-                tab = np.fromfile(os.path.join(d, "ptf_%s_%d.f32" % ("psi" if ptf == 0 else "jnd_hdrvdp", bits)), dtype="<f4")
-            orc = o.Oracle(ptf, bits, o.CS_LUV, 8, 1e4, 0.005, table=tab)
             exp = np.array([orc.quantize(float(v), 0) for v in xs], dtype=np.float32)
             assert np.array_equal(got, exp)
+    assert bad == 0
+    fast.set_stream(None)
+    lit.set_stream(None)
+
+
+@pytest.mark.parametrize("ptf,bits", [(1, 11), (2, 12), (1, 12), (1, 8)])
+def test_encode_kernel_search_equals_bisection_for_every_float(oracle_mod, ptf, bits):
+    """(b): the fused encode kernel, k_encode<CS_RGB, 4:4:4, VW=4, records>.  Frames of 8192 x 4096 pixels whose three
+    planes hold consecutive bit patterns (3 x 2^25 per frame, 43 frames cover 2^32 with wrap-around); profile 3
+    (16-bit 4:4:4) writes one code per input float.  PQ-11 / LOG-12 are BASELINE configs 1 and 4's tables; PQ-8 goes
+    through profile 1 (8-bit samples)."""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    fast, lit = _pair(L, ptf, bits, L.CS_RGB)
+    s = torch.cuda.current_stream().cuda_stream
+    fast.set_stream(s)
+    lit.set_stream(s)
+    profile = 3 if bits > 8 else 1
+    bps = 2 if profile == 3 else 1
+    w, h = 8192, 4096
+    npx = w * h
+    n3 = 3 * npx
+    stride = w * bps
+    psz = h * stride
+    base = torch.arange(n3, dtype=torch.int64, device=dev)
+    pa = [torch.zeros(psz, dtype=torch.uint8, device=dev) for _ in range(3)]
+    pb = [torch.zeros(psz, dtype=torch.uint8, device=dev) for _ in range(3)]
+    orc = _oracle_for(o, ptf, bits, o.CS_RGB)
+    nframes = -(-(1 << 32) // n3)
+    bad = 0
+    for f in range(nframes):
+        bits64 = (base + f * n3) & 0xFFFFFFFF
+        bits32 = torch.where(bits64 >= (1 << 31), bits64 - (1 << 32), bits64).to(torch.int32)
+        x = bits32.view(torch.float32)
+        fast.encode_frames_device(x.data_ptr(), n3, 1, w, h, 1.0, profile, [t.data_ptr() for t in pa], [stride] * 3, [psz] * 3)
+        lit.encode_frames_device(x.data_ptr(), n3, 1, w, h, 1.0, profile, [t.data_ptr() for t in pb], [stride] * 3, [psz] * 3)
+        for p in range(3):
+            bad += int((pa[p] != pb[p]).sum().item())
+        if f in (0, 10, 21, 42):      # literal kernel vs oracle on a strided sample of plane 0
+            idx = torch.arange(0, npx, 131071, device=dev)
+            xs = x[:npx][idx].cpu().numpy()
+            codes = pb[0].view(torch.int16)[idx].cpu().numpy().astype(np.int64) & 0xFFFF if bps == 2 else pb[0][idx].cpu().numpy().astype(np.int64)
+            exp = np.array([orc.quantize(float(v), 0) for v in xs], dtype=np.int64)
+            assert np.array_equal(codes, exp if bps == 2 else exp & 0xFF)
+    assert bad == 0
+    fast.set_stream(None)
+    lit.set_stream(None)
+
+
+@pytest.mark.parametrize("ptf,bits", [(1, 13), (2, 14), (1, 16)])
+def test_global_memory_records_sampled(oracle_mod, ptf, bits):
+    """Tables deeper than 12 bits: records in global memory (mode 4) where the table qualifies, against the literal
+    bisection on the global-memory table (slow: 13-16 dependent loads per value), on 2^22 consecutive bit patterns
+    from every 2^27 boundary plus 2^26 random patterns."""
+    import torch
+    import lumahdrv_amd as L
+    dev = torch.device("cuda:0")
+    lut = L.build_lut(ptf, bits, 1e4, 0.005)
+    fast = L.Context(0)
+    fast.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
+    if fast.quantizer_info()["mode"] != 4:
+        pytest.skip("table does not qualify for records (mode %d)" % fast.quantizer_info()["mode"])
+    os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
+    try:
+        lit = L.Context(0)
+        lit.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
+    finally:
+        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
+    assert lit.quantizer_info()["mode"] == 2
+    s = torch.cuda.current_stream().cuda_stream
+    fast.set_stream(s)
+    lit.set_stream(s)
+    n = 1 << 22
+    a = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+    b = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+    base = torch.arange(n, dtype=torch.int64, device=dev)
+    bad = 0
+    for chunk in range(32):
+        v = (base + chunk * (1 << 27)) & 0xFFFFFFFF
+        x = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32).view(torch.float32)
+        fast.quantize_array_device(x.data_ptr(), a.data_ptr(), n, 0)
+        lit.quantize_array_device(x.data_ptr(), b.data_ptr(), n, 0)
+        bad += int((a[:n] != b[:n]).sum().item())
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (1 << 26,), dtype=torch.int64, device=dev, generator=g).to(torch.int32).view(torch.float32)
+    fast.quantize_array_device(x.data_ptr(), a.data_ptr(), 1 << 26, 0)
+    lit.quantize_array_device(x.data_ptr(), b.data_ptr(), 1 << 26, 0)
+    bad += int((a != b).sum().item())
+    assert bad == 0
+    fast.set_stream(None)
+    lit.set_stream(None)
+
+
+@pytest.mark.parametrize("ptf,bits", TABLES)
+def test_luv_kernel_search_variant_for_every_nonnegative_float_and_positive_nan(oracle_mod, ptf, bits):
+    """(c): quantize_lut<records, 4, POSNAN=true> -- what k_encode<CS_LUV, ...> calls for a row of luminances -- over
+    every bit pattern 0 .. 0x7fffffff, against the literal kernel's POSNAN=false instantiation."""
+    import torch
+    import lumahdrv_amd as L
+    dev = torch.device("cuda:0")
+    fast, lit = _pair(L, ptf, bits, L.CS_LUV)
+    s = torch.cuda.current_stream().cuda_stream
+    fast.set_stream(s)
+    lit.set_stream(s)
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.int16, device=dev)
+    b = torch.empty(n, dtype=torch.int16, device=dev)
+    bad = 0
+    for chunk in range(8):
+        fast.quantize_probe_device(a.data_ptr(), chunk * n, n, posnan=True)
+        lit.quantize_probe_device(b.data_ptr(), chunk * n, n, posnan=False)
+        bad += int((a != b).sum().item())
+    assert bad == 0
+    # and the non-POSNAN instantiation of the same shape on the negative half, sampled
+    for chunk in (8, 11, 15):
+        fast.quantize_probe_device(a.data_ptr(), chunk * n, 1 << 24, posnan=False)
+        lit.quantize_probe_device(b.data_ptr(), chunk * n, 1 << 24, posnan=False)
+        bad += int((a[:1 << 24] != b[:1 << 24]).sum().item())
     assert bad == 0
     fast.set_stream(None)
     lit.set_stream(None)

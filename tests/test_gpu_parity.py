@@ -169,21 +169,28 @@ def test_literal_and_global_lut_modes(L, oracle_mod):
     e, _, _ = orc.encode(f.copy(), 1.0, 2)
     assert all(np.array_equal(a, b) for a, b in zip(planes, e))
     assert same_bits(q.ctx.decode_frame(planes, st, 64, 32, 1.0, 2), orc.decode(e, st, 64, 32, 1.0, 2))
-    # (b) 13-bit PQ table: does not fit the LDS budget -> global-memory bisection
-    q2 = L.LumaQuantizer()
-    q2.setQuantizer(L.PTF_PQ, 13, L.CS_XYZ, 8, 1e4, 0.005)
-    assert q2.ctx.quantizer_info()["mode"] == 2
-    orc2 = o.Oracle(o.PTF_PQ, 13, o.CS_XYZ, 8, 1e4, 0.005)
-    for profile in (2, 3):
-        planes, st, _ = q2.ctx.encode_frame(f, 1.0, profile)
-        e, _, _ = orc2.encode(f.copy(), 1.0, profile)
-        assert all(np.array_equal(a, b) for a, b in zip(planes, e))
-        assert same_bits(q2.ctx.decode_frame(planes, st, 64, 32, 1.0, profile), orc2.decode(e, st, 64, 32, 1.0, profile))
-    # the default tables take the bucketed path
-    q3 = L.LumaQuantizer()
-    q3.setQuantizer(*CONFIGS["pq11_luv8"])
-    info = q3.ctx.quantizer_info()
-    assert info["mode"] == 1 and info["steps"] <= 2
+    # (b) 13-bit PQ table: its threshold records do not fit LDS -> records in global memory (mode 4); the same table
+    #     made non-monotone -> the reference's bisection on the global-memory table (mode 2)
+    lut13 = L.build_lut(L.PTF_PQ, 13).copy()
+    bad13 = lut13.copy()
+    bad13[3000:3010] = bad13[3000:3010][::-1]
+    for table, mode in ((None, 4), (bad13, 2)):
+        q2 = L.LumaQuantizer()
+        q2.setQuantizer(L.PTF_PQ, 13, L.CS_XYZ, 8, 1e4, 0.005, mapping_override=table)
+        assert q2.ctx.quantizer_info()["mode"] == mode
+        orc2 = o.Oracle(o.PTF_PQ, 13, o.CS_XYZ, 8, 1e4, 0.005)
+        if table is not None:
+            orc2.overwrite_mapping(table)
+        for profile in (2, 3):
+            planes, st, _ = q2.ctx.encode_frame(f, 1.0, profile)
+            e, _, _ = orc2.encode(f.copy(), 1.0, profile)
+            assert all(np.array_equal(a, b) for a, b in zip(planes, e))
+            assert same_bits(q2.ctx.decode_frame(planes, st, 64, 32, 1.0, profile), orc2.decode(e, st, 64, 32, 1.0, profile))
+    # the shipped tables take the threshold-record path, in LDS
+    for name in ("pq11_luv8", "log12_luv8", "pq12_rgb", "psi11_luv8"):
+        q3 = L.LumaQuantizer()
+        q3.setQuantizer(*CONFIGS[name])
+        assert q3.ctx.quantizer_info()["mode"] == 3, name
 
 
 def test_unaligned_strides_and_bad_arguments(L, oracle_mod):

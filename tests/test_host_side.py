@@ -107,3 +107,61 @@ def test_lut_search_index_is_sound(L, golden_dir):
     nanlut[7] = np.nan
     assert capi.lut_index(nanlut)["mode"] == 0
     assert capi.lut_index(L.build_lut(L.PTF_PQ, 13))["mode"] == 2
+
+
+def _records_vs_oracle(capi, o, m, orc, rng):
+    ix = capi.thresh_index(m)
+    assert ix["ok"]
+    mid = ((m[:-1].astype(np.float64) + m[1:]) / 2).astype(np.float32)
+    zone = [mid]
+    for _ in range(6):
+        zone.append(np.nextafter(zone[-1], np.float32(np.inf)))
+    dn = mid
+    for _ in range(6):
+        dn = np.nextafter(dn, np.float32(-np.inf))
+        zone.append(dn)
+    v = np.concatenate([m, np.nextafter(m, np.float32(np.inf)), np.nextafter(m, np.float32(-np.inf))] + zone + [
+        np.exp(rng.uniform(np.log(1e-8), np.log(1e9), 400000)).astype(np.float32),
+        np.array([0.0, -0.0, -1.0, 1e-45, 1e-39, 3e38, np.inf, -np.inf, np.nan, -1e-30, 65504.0], dtype=np.float32)])
+    v = np.where(np.isnan(v), np.float32(np.nan), v).astype(np.float32)     # numpy's nan is sign-clear
+    v = np.concatenate([v, np.ones((-v.size) % 4, dtype=np.float32)])
+    got = capi.thresh_lookup(ix, v)
+    frame = np.stack([v.reshape(2, -1)] * 3).copy()
+    planes, _, _ = orc.encode(frame, 1.0, 3)               # CS_RGB, profile 3: every value straight through the search
+    exp = planes[0].view("<u2")[:, :frame.shape[2]].reshape(-1).astype(np.int64)
+    assert np.array_equal(got, exp)
+    return ix
+
+
+def test_threshold_records_equal_the_reference_search(L, oracle_mod, golden_dir):
+    """The threshold records the kernels search with (lut_index.hpp; one 4-byte gather per value) against the oracle's
+    literal bisection + nearest-of-two (src/luma_quantizer.cpp:222-235) on the values where they could differ: every
+    table entry and its neighbours, the rounding-tie zone around every midpoint, a dense log-uniform sample and the
+    specials.  (The GPU suite repeats this for all 2^32 bit patterns through the kernels themselves.)"""
+    from lumahdrv_amd import capi
+    from tests.golden.make_golden import CONFIGS
+    o = oracle_mod
+    g = np.load(os.path.join(golden_dir, "ref_luts.npz"))
+    rng = np.random.default_rng(1)
+    for name, cfg in CONFIGS.items():
+        m = g[name]
+        orc = o.Oracle(cfg[0], cfg[1], o.CS_RGB, cfg[3], cfg[4], cfg[5], table=m if cfg[0] in (0, 3) else None)
+        ix = _records_vs_oracle(capi, o, m, orc, rng)
+        assert ix["nbuckets"] * 4 <= (72 << 10) or cfg[0] == L.PTF_LINEAR, name      # fits LDS (LINEAR: L2-resident)
+    # duplicate entries are still a monotone step function
+    dup = g["pq11_luv8"].copy()
+    dup[5] = dup[4]
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_RGB, 8, 1e4, 0.005)
+    orc.overwrite_mapping(dup)
+    _records_vs_oracle(capi, o, dup, orc, rng)
+    dup[900:903] = dup[900]                       # a triple makes the code jump by two at one float: literal path
+    assert not capi.thresh_index(dup)["ok"]
+    # tables the records cannot represent: the kernels run the literal bisection
+    bad = g["pq11_luv8"].copy()
+    bad[100], bad[101] = bad[101], bad[100]
+    assert not capi.thresh_index(bad)["ok"]
+    nanlut = g["pq11_luv8"].copy()
+    nanlut[7] = np.nan
+    assert not capi.thresh_index(nanlut)["ok"]
+    ix13 = capi.thresh_index(L.build_lut(L.PTF_PQ, 13))
+    assert ix13["ok"] and ix13["nbuckets"] * 4 > (72 << 10)                         # global-memory records
