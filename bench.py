@@ -59,12 +59,12 @@ def parse():
 WORKLOADS = {
     # name: (ptf, bits, cs, bitsC, maxLum, minLum, preScaling, profile, description)
     "pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0, 2, "PQ 11-bit Lu'v' 8-bit chroma, profile 2 (4:2:0 16-bit)",
-                 "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,bucketed LUT 1 step>"),
+                 "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
     "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0, 2, "HDR10 recipe: PQ 10-bit YCbCr BT.2020 10-bit chroma, max/min 1000/0.01, preScaling 20",
                    "RGB->PQ->Y'CbCr (8 glibc-exact powf per pixel: fp64-VALU-bound, not HBM-bound)",
-                   "lh::k_encode<CS_YCBCR,4:2:0,VW=4,bucketed LUT>"),
+                   "lh::k_encode<CS_YCBCR,4:2:0,VW=4,LDS threshold records>"),
     "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0, 2, "LOG 12-bit Lu'v' 8-bit chroma, profile 2",
-                  "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,bucketed LUT 2 steps>"),
+                  "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
 }
 
 

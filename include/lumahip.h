@@ -84,13 +84,6 @@ int lumahip_set_quantizer(lumahip_ctx *ctx, int ptf, unsigned bitdepth, int colo
  * reference reads out of bounds there), LUMAHIP_ERR_STATE if a data table cannot be read. */
 int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, float *lut_out, size_t lut_len);
 
-/* Host-only (no GPU, no context): the search index lumahip_set_quantizer would build for `lut`.
- * info[0] = mode (as in lumahip_quantizer_info), info[1] = right shift applied to the fp32 bit pattern,
- * info[2] = key of bucket 0, info[3] = refinement steps, info[4] = number of buckets (the last one is the "above
- * the whole table" bucket whose entry is maxVal); start_out (nullable, start_cap entries, pass >= 8192) receives
- * the per-bucket byte offsets (4 x first candidate index). */
-int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *start_out, size_t start_cap);
-
 /* Host-only (no GPU, no context): the threshold records lumahip_set_quantizer builds for a monotone finite table
  * (lumahdrv_amd/csrc/lut_index.hpp): quantize(v) = (rec[clamp(bits(v) >> shift, kmin, kmin+nbuckets-1) - kmin]
  * + (bits(v) & (2^shift - 1))) >> shift for every float that is not a sign-set NaN (those give maxVal).
@@ -100,10 +93,9 @@ int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *st
 int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
 
 /* introspection of the search index built for the current LUT (tests):
- * info[0] = mode (0 = literal bisection, LUT in LDS; 1 = two-level bucketed search (LUMAHIP_SEARCH=bucket only);
- *                 2 = literal bisection, LUT read from global memory (bitdepth > 12);
- *                 3 = threshold records in LDS; 4 = threshold records in global memory),
- * info[1] = mantissa bits of the bucket key, info[2] = number of buckets, info[3] = refinement steps,
+ * info[0] = mode (0 = literal bisection, table in LDS; 2 = literal bisection, table read from global memory
+ *                 (bitdepth > 12); 3 = threshold records in LDS; 4 = threshold records in global memory),
+ * info[1] = mantissa bits of the record key, info[2] = number of records, info[3] = key shift,
  * info[4] = LDS bytes per workgroup of the encode-side kernels */
 int lumahip_quantizer_info(const lumahip_ctx *ctx, int info[5]);
 
@@ -196,10 +188,10 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
                           const size_t plane_frame_stride[3], float *avg_ms);
 
 /* Test probe: the luminance search exactly as the encode kernels instantiate it (four values per thread, the
- * context's search mode; posnan != 0 selects the Lu'v' kernels' variant, which relies on NaNs being sign-clear)
+ * context's search mode; nonneg != 0 selects the Lu'v' kernels' variant, which relies on every value being >= 0 or NaN)
  * over the n consecutive fp32 bit patterns first_bits, first_bits+1, ...: out_dev[i] = code.  n % 4 == 0.
  * Counterpart of LumaQuantizer::quantize(val, 0) (src/luma_quantizer.cpp:222-235). */
-int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int posnan);
+int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg);
 
 /* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
  * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the

@@ -19,7 +19,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_lut_index_host", "lumahip_thresh_index_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device",
@@ -85,7 +85,6 @@ def lib():
     L.lumahip_sync.argtypes = [vp]
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
-    L.lumahip_lut_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_thresh_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
@@ -137,17 +136,6 @@ def build_lut(ptf: int, bitdepth: int, max_lum: float = 1e4, min_lum: float = 0.
     if rc != OK:
         raise LumaHipError(rc, "lumahip_build_lut(ptf=%d, bitdepth=%d) failed" % (ptf, bitdepth))
     return out
-
-
-def lut_index(lut: np.ndarray):
-    """host-only: (mode, shift, kmin, steps, start[]) of the bucketed search index for a table (no GPU needed)"""
-    lut = np.ascontiguousarray(lut, dtype=np.float32)
-    info = (C.c_int * 5)()
-    start = np.zeros(8192, dtype=np.uint16)
-    rc = lib().lumahip_lut_index_host(lut.ctypes.data, lut.size, info, start.ctypes.data, start.size)
-    if rc != OK:
-        raise LumaHipError(rc, "lumahip_lut_index_host failed")
-    return dict(mode=info[0], shift=info[1], kmin=info[2], steps=info[3], nbuckets=info[4], start=start[:info[4]].copy())
 
 
 def thresh_index(lut: np.ndarray):
@@ -225,7 +213,7 @@ class Context:
     def quantizer_info(self):
         a = (C.c_int * 5)()
         self._chk(self.L.lumahip_quantizer_info(self.h, a))
-        return dict(mode=a[0], mant_bits=a[1], buckets=a[2], steps=a[3], lds_bytes=a[4])
+        return dict(mode=a[0], mant_bits=a[1], buckets=a[2], shift=a[3], lds_bytes=a[4])
 
     # ---- host entry points (numpy)
     def encode_frame(self, rgb: np.ndarray, sc=1.0, profile=2, align=32, want_transformed=False, strides=None):
@@ -370,9 +358,9 @@ class Context:
     def powf_probe_device(self, out_ptr, first_bits, n, y, regular=True):
         self._chk(self.L.lumahip_powf_probe_device(self.h, out_ptr, first_bits, n, y, int(bool(regular))))
 
-    def quantize_probe_device(self, out_ptr, first_bits, n, posnan=False):
-        """uint16 codes of the n consecutive fp32 bit patterns from first_bits, through quantize_lut<mode, 4, posnan>"""
-        self._chk(self.L.lumahip_quantize_probe_device(self.h, out_ptr, first_bits, n, int(bool(posnan))))
+    def quantize_probe_device(self, out_ptr, first_bits, n, nonneg=False):
+        """uint16 codes of the n consecutive fp32 bit patterns from first_bits, through quantize_lut<mode, 4, nonneg>"""
+        self._chk(self.L.lumahip_quantize_probe_device(self.h, out_ptr, first_bits, n, int(bool(nonneg))))
 
     def host_register(self, arr: np.ndarray):
         """pin a numpy array's memory for PCIe-rate transfers by the host entry points"""

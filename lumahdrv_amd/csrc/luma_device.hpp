@@ -29,8 +29,16 @@ enum : int { CS_LUV = 0, CS_RGB = 1, CS_YCBCR = 2, CS_XYZ = 3, CS_PACK = 4 };
 LH_DEV float std_min(float a, float b) { return (b < a) ? b : a; }
 LH_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
 
-// std::max(std::min(v, 1e8f), 1e-4f): src/luma_quantizer.cpp:285-287,305-307,412-414
-LH_DEV float clamp_xyz(float v) { return std_max(std_min(v, 100000000.0f), 0.0001f); }
+// std::max(std::min(v, 1e8f), 1e-4f): src/luma_quantizer.cpp:285-287,305-307,412-414.  libstdc++'s min / max return
+// their FIRST argument when a comparison with NaN is false, so a NaN v passes through both; every other v (+-inf
+// included) is clamped.  That is exactly IEEE-754-2019 maximum(minimum(v, 1e8), 1e-4) with its NaN propagation --
+// gfx950's v_minimum3_f32 / v_maximum3_f32 (two instructions, no compare + select pairs, no separate NaN test;
+// v_min_f32 / v_max_f32 / v_med3_f32 would return the non-NaN operand).  A NaN's sign / payload may differ from the
+// x86 result, as everywhere (see the header comment).
+LH_DEV float clamp_xyz(float v)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_minimum(v, 100000000.0f), 0.0001f);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Division.
@@ -173,18 +181,11 @@ LH_DEVS void xform_fwd<CS_XYZ>(float r, float g, float b, const XformConst &k, f
 template <>
 LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    // The three matrix rows have strictly positive coefficients whose first two sum to < 1, so the raw X, Y, Z
-    // are NaN together or not at all (a NaN input, or +inf and -inf inputs; overflow can only give +-inf).
-    // Non-NaN values take the 1-instruction clamp v_med3_f32(v, 1e-4, 1e8) == max(min(v,1e8),1e-4); in the
-    // NaN case the reference's std::min/max pass the NaN through, so the raw (NaN) values are selected back
-    // and NaN then propagates through the rest of the arithmetic exactly as it does in the reference.
-    const float Xr = (0.412424f * r + 0.357579f * g) + 0.180464f * b;
-    const float Yr = (0.212656f * r + 0.715158f * g) + 0.072186f * b;
-    const float Zr = (0.019332f * r + 0.119193f * g) + 0.950444f * b;
-    const bool any_nan = (Yr != Yr);
-    const float X = any_nan ? Xr : __builtin_amdgcn_fmed3f(Xr, 0.0001f, 100000000.0f);
-    const float Y = any_nan ? Yr : __builtin_amdgcn_fmed3f(Yr, 0.0001f, 100000000.0f);
-    const float Z = any_nan ? Zr : __builtin_amdgcn_fmed3f(Zr, 0.0001f, 100000000.0f);
+    // a NaN among r, g, b makes X, Y, Z NaN; clamp_xyz passes it on and it then propagates through the rest of
+    // the arithmetic exactly as it does in the reference (Y -> code maxVal, u', v' -> code maxC)
+    const float X = clamp_xyz((0.412424f * r + 0.357579f * g) + 0.180464f * b);
+    const float Y = clamp_xyz((0.212656f * r + 0.715158f * g) + 0.072186f * b);
+    const float Z = clamp_xyz((0.019332f * r + 0.119193f * g) + 0.950444f * b);
     const float sum = (X + Y) + Z;
     // X,Y,Z in [1e-4,1e8] (or NaN) after the clamp, sum in [3e-4,3e8]: div_nr is exact here
     const float rs = rcp_nr(sum);
@@ -194,7 +195,7 @@ LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, f
     const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
     const float rd = rcp_nr(den);
     // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410: div_255_pos is exact
-    c0 = any_nan ? __builtin_nanf("") : Y;  // sign-clear NaN for the table search (POSNAN); a NaN either way
+    c0 = Y;  // >= 1e-4, or a NaN of either sign: the luminance search is told so (NONNEG)
     c1 = div_255_pos(div_nr_r(4.0f * x, den, rd) * 410.f);
     c2 = div_255_pos(div_nr_r(9.0f * y, den, rd) * 410.f);
 }
@@ -387,13 +388,12 @@ LH_DEVS void xform_inv<CS_RGB>(float c0, float c1, float c2, const XformConst &k
 // ---------------------------------------------------------------------------------------------------
 struct QuantDev {
     const float *lut;        // global: maxVal+1 floats followed by `pad` NaNs
-    const uint16_t *bucket;  // global: nbuckets bucket starts (mode 1)
     const uint32_t *rec;     // global: nbuckets threshold records (modes 3, 4; lut_index.hpp)
     int lut_len;             // maxVal + 1
     int pad;
     int maxVal;
     int mode;                // lh::LutMode
-    int shift, kmin, nbuckets, steps;
+    int shift, kmin, nbuckets;  // threshold records: key = bits >> shift, clamped to [kmin, kmin+nbuckets-1]
     float maxC;              // (float)m_maxValColor
     int cs;
     float Lmax;
@@ -428,7 +428,7 @@ LH_DEV float dequantize_lut(int code, LutPtr lut, int maxVal)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LUT-channel quantizer for N values at once (interleaved so the LDS probes of the N searches overlap).
+// LUT-channel quantizer for N values at once.
 // ---------------------------------------------------------------------------------------------------
 
 // the reference's loop, literally: src/luma_quantizer.cpp:222-235
@@ -446,15 +446,6 @@ LH_DEV int quantize_lut_literal(float v, LutPtr lut, int maxVal)
     return ((v - lut[l]) < (lut[r] - v)) ? l : r;
 }
 
-// Bucketed search (see lut_index.hpp).  `bucket[k]` holds the BYTE offset (4*start) of the first candidate
-// entry of key k; the table is followed by NaN padding, so probes past maxVal compare false and
-// lut[maxVal+1] reads NaN.  Result for every v (NaN, +-inf, negatives, denormals included) equals the
-// reference's bisection + nearest-of-two (src/luma_quantizer.cpp:222-235):
-//   * l = start + (number of further entries <= v)  -- unclamped, so l == maxVal when v >= map[maxVal];
-//     then mr = NaN, the nearest test is false, code = maxVal+1, and the final min() gives maxVal, which
-//     is what the reference returns (l = maxVal-1, r = maxVal, "v - map[l] < map[r] - v" is false);
-//   * NaN: every `v < map[m]` of the reference is false, so it returns maxVal; here l is forced to maxVal.
-// STEPS >= 0: compile-time number of refinement probes; STEPS < 0: q.steps at run time.
 LH_DEV float lds_f32(const float *lut, int byte_off)
 {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut) + byte_off);
@@ -468,84 +459,24 @@ LH_DEV int med3_i32(int x, int lo, int hi)
     return r;
 }
 
-// POSNAN: the caller guarantees that a NaN among v[] has its sign bit clear (then its key exceeds every finite
-// key and the top bucket, whose entry is maxVal, yields the reference's answer without a separate NaN test).
-template <int N, int STEPS, bool POSNAN, typename LutPtr, typename BucketPtr>
-LH_DEV void quantize_lut_bucket(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
+// unsigned median of three (lo <= hi)
+LH_DEV uint32_t med3_u32(uint32_t x, uint32_t lo, uint32_t hi)
 {
-    int l4[N];
-    const int maxVal4 = q.maxVal * 4;
-    // the table has nbuckets entries for keys kmin .. kmin+nbuckets-1 (the last one is the "above everything"
-    // bucket = maxVal); index it with the clamped raw key through a pre-biased base
-    const auto biased = bucket - q.kmin;
-    const int khi = q.kmin + q.nbuckets - 1;
-#pragma unroll
-    for (int i = 0; i < N; i++)
-        l4[i] = biased[med3_i32(__float_as_int(v[i]) >> q.shift, q.kmin, khi)];
-    if constexpr (STEPS == 1) {
-        // one refinement probe: fetch map[l], map[l+1], map[l+2] at once and select
-        float a[N], b[N], c[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            if constexpr (!POSNAN)
-                l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];
-            a[i] = lds_f32(lut, l4[i]);
-            b[i] = lds_f32(lut, l4[i] + 4);
-            c[i] = lds_f32(lut, l4[i] + 8);
-        }
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const bool t = (b[i] <= v[i]);
-            const float ml = t ? b[i] : a[i];
-            const float mr = t ? c[i] : b[i];
-            const int l = (l4[i] >> 2) + (t ? 1 : 0);
-            const int cc = ((v[i] - ml) < (mr - v[i])) ? l : l + 1;
-            code[i] = min(cc, q.maxVal);
-        }
-    } else {
-        if constexpr (STEPS >= 0) {
-#pragma unroll
-            for (int s = STEPS - 1; s >= 0; --s) {
-                float m[N];
-#pragma unroll
-                for (int i = 0; i < N; i++)
-                    m[i] = lds_f32(lut, l4[i] + (4 << s));
-#pragma unroll
-                for (int i = 0; i < N; i++)
-                    l4[i] = (m[i] <= v[i]) ? l4[i] + (4 << s) : l4[i];
-            }
-        } else {
-            for (int s = q.steps - 1; s >= 0; --s) {
-                float m[N];
-#pragma unroll
-                for (int i = 0; i < N; i++)
-                    m[i] = lds_f32(lut, l4[i] + (4 << s));
-#pragma unroll
-                for (int i = 0; i < N; i++)
-                    l4[i] = (m[i] <= v[i]) ? l4[i] + (4 << s) : l4[i];
-            }
-        }
-        float ml[N], mr[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            l4[i] = (v[i] != v[i]) ? maxVal4 : l4[i];  // (probes may have moved a +NaN's l4 nowhere: keep the test)
-            ml[i] = lds_f32(lut, l4[i]);
-            mr[i] = lds_f32(lut, l4[i] + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const int l = l4[i] >> 2;
-            const int cc = ((v[i] - ml[i]) < (mr[i] - v[i])) ? l : l + 1;
-            code[i] = min(cc, q.maxVal);
-        }
-    }
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
+    return r;
 }
 
 // Threshold records (lut_index.hpp, "Threshold records"): code = (rec[clamped key] + low bits of v) >> shift --
 // one 4-byte gather, no table probes, no subtractions; equal to the reference's bisection + nearest-of-two for
-// every float by construction of the records (host) and by the exhaustive sweep of tests/test_gpu_exhaustive.py.
-// `rec` points at the record of key kmin (LDS copy or global).  POSNAN: see quantize_lut_bucket.
-template <int N, bool POSNAN, typename RecPtr>
+// every float by construction of the records (host) and by the exhaustive sweeps of tests/test_gpu_exhaustive.py.
+// `rec` points at the record of key kmin >= 0 (LDS copy or global).
+// NONNEG = false: any float.  The key is the SIGNED bit pattern >> shift, so negative values (and sign-set NaNs) clamp
+//          to the bottom bucket; the reference answers maxVal for every NaN, hence the explicit NaN test.
+// NONNEG = true: the caller guarantees v >= 0 or v is a NaN of EITHER sign (the Lu'v' luminance: clamped to >= 1e-4
+//          or NaN).  The key is the UNSIGNED bit pattern >> shift: every NaN exceeds every finite key and lands in the
+//          top bucket (start maxVal, no threshold), no NaN test needed.
+template <int N, bool NONNEG, typename RecPtr>
 LH_DEV void quantize_thresh(const float (&v)[N], int (&code)[N], RecPtr rec, const QuantDev &q)
 {
     const auto biased = rec - q.kmin;
@@ -553,31 +484,29 @@ LH_DEV void quantize_thresh(const float (&v)[N], int (&code)[N], RecPtr rec, con
     const uint32_t lowmask = (1u << q.shift) - 1u;  // shift <= 23
     uint32_t r[N];
 #pragma unroll
-    for (int i = 0; i < N; i++)
-        r[i] = biased[med3_i32(__float_as_int(v[i]) >> q.shift, q.kmin, khi)];
+    for (int i = 0; i < N; i++) {
+        if constexpr (NONNEG)
+            r[i] = biased[med3_u32(__float_as_uint(v[i]) >> q.shift, (uint32_t)q.kmin, (uint32_t)khi)];
+        else
+            r[i] = biased[med3_i32(__float_as_int(v[i]) >> q.shift, q.kmin, khi)];
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int c = (int)((r[i] + (__float_as_uint(v[i]) & lowmask)) >> q.shift);
-        if constexpr (POSNAN)
+        if constexpr (NONNEG)
             code[i] = c;
         else
-            code[i] = (v[i] != v[i]) ? q.maxVal : c;  // a sign-set NaN's key clamps to the bottom bucket
+            code[i] = (v[i] != v[i]) ? q.maxVal : c;
     }
 }
 
-// MODE: 0 literal bisection (LDS), 2 literal bisection (global), 1 bucketed with run-time step count,
-//       11 / 12 bucketed with 1 / 2 compile-time steps, 3 / 4 threshold records (LDS / global; `bucket` = records)
-template <int MODE, int N, bool POSNAN = false, typename LutPtr, typename BucketPtr>
-LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, BucketPtr bucket, const QuantDev &q)
+// MODE (lut_index.hpp LutMode): 0 literal bisection (table in LDS), 2 literal bisection (table in global memory),
+//       3 / 4 threshold records (LDS / global); `idx` = the records for 3 / 4, unused otherwise
+template <int MODE, int N, bool NONNEG = false, typename LutPtr, typename IdxPtr>
+LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, IdxPtr idx, const QuantDev &q)
 {
     if constexpr (MODE == 3 || MODE == 4) {
-        quantize_thresh<N, POSNAN>(v, code, bucket, q);
-    } else if constexpr (MODE == 1) {
-        quantize_lut_bucket<N, -1, POSNAN>(v, code, lut, bucket, q);
-    } else if constexpr (MODE == 11) {
-        quantize_lut_bucket<N, 1, POSNAN>(v, code, lut, bucket, q);
-    } else if constexpr (MODE == 12) {
-        quantize_lut_bucket<N, 2, POSNAN>(v, code, lut, bucket, q);
+        quantize_thresh<N, NONNEG>(v, code, idx, q);
     } else {
 #pragma unroll
         for (int i = 0; i < N; i++)

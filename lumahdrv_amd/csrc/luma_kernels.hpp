@@ -9,8 +9,8 @@
 // thread owns one unit per tile; a wave owns 64 consecutive units of one row pair (64*VW*4 B = 1 KiB
 // contiguous per load instruction per row and channel); a workgroup of NW waves owns a tile of
 // 64*VW pixels x 2*NW rows; workgroups are persistent and stride over tiles (tile index is
-// wave-uniform, so all index arithmetic on it is scalar).  The transfer-function table and its bucket
-// index are staged once per workgroup in LDS.  No inter-workgroup communication except the optional
+// wave-uniform, so all index arithmetic on it is scalar).  The luminance search records (encode) /
+// the transfer-function table (decode) are staged once per workgroup in LDS.  No inter-workgroup communication except the optional
 // per-frame statistics (float atomics).
 #pragma once
 
@@ -69,12 +69,11 @@ struct DecArgs {
     int do_tmo, ldr_sim;
 };
 
-// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][bucket: nbuckets u16 | records: nbuckets u32, rounded to
-// 16 B][powf tables].  Which parts a kernel stages is a compile-time set.
-enum : int { STAGE_LUT = 1, STAGE_BUCKET = 2, STAGE_REC = 4, STAGE_POWF = 8 };
+// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][records: nbuckets u32, rounded to 16 B][powf tables].
+// Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
+enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8 };
 
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
-LH_DEV int lds_bucket_bytes(const QuantDev &q) { return (q.nbuckets * 2 + 15) & ~15; }
 LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
 
 template <int WHAT>
@@ -90,14 +89,6 @@ LH_DEV int stage_tables(unsigned char *smem, const QuantDev &q)
         for (int i = tid; i < n4; i += nt)
             s[i] = g[i];
         off += lds_lut_bytes(q);
-    }
-    if constexpr (WHAT & STAGE_BUCKET) {
-        const int b4 = lds_bucket_bytes(q) / 16;
-        const uint4 *gb = reinterpret_cast<const uint4 *>(q.bucket);
-        uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
-        for (int i = tid; i < b4; i += nt)
-            sb[i] = gb[i];
-        off += lds_bucket_bytes(q);
     }
     if constexpr (WHAT & STAGE_REC) {
         const int b4 = lds_rec_bytes(q) / 16;  // the device buffer is padded to 16 B
@@ -252,7 +243,7 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 
 // ---- ENCODE ---------------------------------------------------------------------------------------
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
-// LM: LUT search mode (0 literal/LDS, 2 literal/global, 1 bucketed run-time steps, 11/12 bucketed 1/2 steps).
+// LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global).
 //
 // Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued while the current
 // unit is still being searched / packed / stored (without this the kernel sat at ~45 % SQ_WAIT_ANY,
@@ -339,7 +330,7 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
 // quantize + subsample + pack + store one transformed unit
 template <int CS, bool SUB, int VW, int LM, typename LutPtr, typename IdxPtr>
 LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const float (&c1)[2 * VW],
-                     const float (&c2)[2 * VW], const EncArgs &a, LutPtr lut, IdxPtr s_bucket)
+                     const float (&c2)[2 * VW], const EncArgs &a, LutPtr lut, IdxPtr idx)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);  // planes 1,2 also go through the LUT
     const float maxC = a.q.maxC;
@@ -355,7 +346,7 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
 #pragma unroll
             for (int i = 0; i < VW; i++)
                 v[i] = c0[r * VW + i];
-            quantize_lut<LM, VW, CS == CS_LUV>(v, row, lut, s_bucket, a.q);  // Lu'v': Y is positive or a sign-clear NaN
+            quantize_lut<LM, VW, CS == CS_LUV>(v, row, lut, idx, a.q);  // Lu'v': Y is >= 1e-4 or NaN
             store_samples<VW>(d + (size_t)r * a.stride[0], row, a.bps, a.aligned);
         }
     }
@@ -372,8 +363,8 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
         }
         int k1[NQ], k2[NQ];
         if constexpr (LUT_ALL) {
-            quantize_lut<LM, NQ>(a1, k1, lut, s_bucket, a.q);
-            quantize_lut<LM, NQ>(a2, k2, lut, s_bucket, a.q);
+            quantize_lut<LM, NQ>(a1, k1, lut, idx, a.q);
+            quantize_lut<LM, NQ>(a2, k2, lut, idx, a.q);
         } else {
 #pragma unroll
             for (int qd = 0; qd < NQ; qd++) {
@@ -388,8 +379,8 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
     } else {
         int k1[2 * VW], k2[2 * VW];
         if constexpr (LUT_ALL) {
-            quantize_lut<LM, 2 * VW>(c1, k1, lut, s_bucket, a.q);
-            quantize_lut<LM, 2 * VW>(c2, k2, lut, s_bucket, a.q);
+            quantize_lut<LM, 2 * VW>(c1, k1, lut, idx, a.q);
+            quantize_lut<LM, 2 * VW>(c2, k2, lut, idx, a.q);
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * VW; j++) {
@@ -417,15 +408,11 @@ template <int CS, bool SUB, int VW, int LM>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool LUT_LDS = (LM == 0 || LM == 1 || LM == 11 || LM == 12);
-    constexpr bool BUCKETED = (LM == 1 || LM == 11 || LM == 12);
-    constexpr int WHAT = (LUT_LDS ? STAGE_LUT : 0) | (BUCKETED ? STAGE_BUCKET : 0) | (LM == 3 ? STAGE_REC : 0) |
-                         (CS == CS_YCBCR ? STAGE_POWF : 0);
+    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | (LM == 3 ? STAGE_REC : 0) | (CS == CS_YCBCR ? STAGE_POWF : 0);
     const int pw_off = stage_tables<WHAT>(smem, a.q);
 
-    const float *s_lut = reinterpret_cast<const float *>(smem);
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
-    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);  // LM == 3: the records are all there is
+    const float *s_lut = reinterpret_cast<const float *>(smem);        // LM == 0
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);  // LM == 3
     XformConst k;
     k.sc = a.sc;
     k.Lmax = a.q.Lmax;
@@ -466,10 +453,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
             else if constexpr (LM == 4)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, a.q.rec);
-            else if constexpr (LUT_LDS)
-                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_bucket);
+            else if constexpr (LM == 0)
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
             else
-                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_bucket);
+                enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_rec);
         }
     }
     if (a.stats)
@@ -778,10 +765,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WHAT = (MODE == 0 || MODE == 1) ? (STAGE_LUT | (MODE == 1 ? STAGE_BUCKET : 0)) : (MODE == 3 ? STAGE_REC : 0);
-    stage_tables<WHAT>(smem, a.q);
+    stage_tables<(MODE == 0 ? STAGE_LUT : 0) | (MODE == 3 ? STAGE_REC : 0)>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(a.q));
     const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const float v[1] = {a.in[i]};
@@ -792,28 +777,23 @@ __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
             quantize_lut<3, 1>(v, c, s_lut, s_rec, a.q);     // any NaN sign
         else if constexpr (MODE == 4)
             quantize_lut<4, 1>(v, c, a.q.lut, a.q.rec, a.q);
-        else if constexpr (MODE == 1)
-            quantize_lut<1, 1>(v, c, s_lut, s_bucket, a.q);  // run-time step count, any NaN sign
         else if constexpr (MODE == 0)
-            quantize_lut<0, 1>(v, c, s_lut, s_bucket, a.q);
+            quantize_lut<0, 1>(v, c, s_lut, s_rec, a.q);
         else
-            quantize_lut<2, 1>(v, c, a.q.lut, s_bucket, a.q);
+            quantize_lut<2, 1>(v, c, a.q.lut, s_rec, a.q);
         a.out[i] = (float)c[0];
     }
 }
 
-// Test probe: quantize_lut<LM, 4, POSNAN> -- the instantiation the Lu'v' encode kernels call for a row of four
-// luminances -- over consecutive fp32 bit patterns (tests/test_gpu_exhaustive.py; POSNAN promises that a NaN has
-// its sign bit clear, so the sweep covers 0 .. 0x7fffffff).
-template <int LM, bool POSNAN>
+// Test probe: quantize_lut<LM, 4, NONNEG> -- the instantiation the Lu'v' encode kernels call for a row of four
+// luminances -- over consecutive fp32 bit patterns (tests/test_gpu_exhaustive.py; NONNEG promises v >= 0 or NaN, so
+// that sweep covers 0 .. 0x7fffffff plus the sign-set NaNs 0xff800001 .. 0xffffffff).
+template <int LM, bool NONNEG>
 __global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16_t *out, uint32_t first_bits, size_t n4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool LUT_LDS = (LM == 0 || LM == 1 || LM == 11 || LM == 12);
-    constexpr bool BUCKETED = (LM == 1 || LM == 11 || LM == 12);
-    stage_tables<(LUT_LDS ? STAGE_LUT : 0) | (BUCKETED ? STAGE_BUCKET : 0) | (LM == 3 ? STAGE_REC : 0)>(smem, q);
+    stage_tables<(LM == 0 ? STAGE_LUT : 0) | (LM == 3 ? STAGE_REC : 0)>(smem, q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(smem + lds_lut_bytes(q));
     const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float v[4];
@@ -822,13 +802,13 @@ __global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16
         for (int j = 0; j < 4; j++)
             v[j] = __uint_as_float(first_bits + (uint32_t)(4 * i + j));
         if constexpr (LM == 3)
-            quantize_lut<LM, 4, POSNAN>(v, c, s_lut, s_rec, q);
+            quantize_lut<LM, 4, NONNEG>(v, c, s_lut, s_rec, q);
         else if constexpr (LM == 4)
-            quantize_lut<LM, 4, POSNAN>(v, c, q.lut, q.rec, q);
-        else if constexpr (LUT_LDS)
-            quantize_lut<LM, 4, POSNAN>(v, c, s_lut, s_bucket, q);
+            quantize_lut<LM, 4, NONNEG>(v, c, q.lut, q.rec, q);
+        else if constexpr (LM == 0)
+            quantize_lut<LM, 4, NONNEG>(v, c, s_lut, s_rec, q);
         else
-            quantize_lut<LM, 4, POSNAN>(v, c, q.lut, s_bucket, q);
+            quantize_lut<LM, 4, NONNEG>(v, c, q.lut, s_rec, q);
         store_samples<4>(reinterpret_cast<unsigned char *>(out + 4 * i), c, 2, 1);
     }
 }

@@ -30,10 +30,8 @@ struct lumahip_ctx {
     int ptf = 0;
     unsigned bitdepth = 0, bitdepthC = 0;
     QuantDev q{};
-    LutIndex idx;
     ThreshIndex tix;
     float *d_lut = nullptr;
-    uint16_t *d_bucket = nullptr;
     uint32_t *d_rec = nullptr;
     bool lut_in_lds = true;  // decode side: tables up to 12 bits are staged in LDS
     float minLum = 0.0f;
@@ -145,7 +143,6 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_bucket);
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
@@ -215,45 +212,25 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
 
     // Search index.  Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit
     // LUMAHIP_REC_LDS_MAX (two 1024-thread workgroups per CU then still fit the 160 KiB), else in global memory
-    // (L2-resident).  Anything else (NaNs, decreasing or duplicate entries -- a decoder
-    // may be handed any attachment-434 table) runs the reference's bisection literally.  Environment hooks for the
-    // tests and for A/B measurements: LUMAHIP_FORCE_LITERAL, LUMAHIP_SEARCH=bucket (the round-1 two-level search).
-    const char *search_env = getenv("LUMAHIP_SEARCH");
-    const bool want_bucket = search_env && !strcmp(search_env, "bucket");
+    // (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table)
+    // runs the reference's bisection literally.  LUMAHIP_FORCE_LITERAL is the tests' hook for that path.
     c->tix = ThreshIndex();
-    c->idx = LutIndex();
     c->lut_in_lds = (n <= 4096);
     int mode = c->lut_in_lds ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
     if (!getenv("LUMAHIP_FORCE_LITERAL")) {
-        if (want_bucket) {
-            c->idx = build_lut_index(lut, (int)n);
-            mode = c->idx.mode;
-        } else {
-            c->tix = build_thresh_index(lut, (int)n, 1 << 19);
-            if (c->tix.ok)
-                mode = (c->tix.rec.size() * 4 <= LUMAHIP_REC_LDS_MAX) ? LUT_THRESH_LDS : LUT_THRESH_GLOBAL;
-        }
+        c->tix = build_thresh_index(lut, (int)n, 1 << 19);
+        if (c->tix.ok)
+            mode = (c->tix.rec.size() * 4 <= LUMAHIP_REC_LDS_MAX) ? LUT_THRESH_LDS : LUT_THRESH_GLOBAL;
     }
-    c->idx.mode = mode;
-    const LutIndex &ix = c->idx;
-    const size_t lut_floats = ((n + std::max(ix.pad, 1)) + 3) & ~(size_t)3;
+    const size_t lut_floats = (n + 1 + 3) & ~(size_t)3;  // NaN padding up to a multiple of 16 bytes
     std::vector<float> padded(lut_floats, __builtin_nanf(""));
     memcpy(padded.data(), lut, n * sizeof(float));
     (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_bucket);
     (void)hipFree(c->d_rec);
     c->d_lut = nullptr;
-    c->d_bucket = nullptr;
     c->d_rec = nullptr;
     HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
-    const size_t nb = mode == LUT_BUCKET_LDS ? (((size_t)ix.nbuckets + 7) & ~(size_t)7) : 0;
-    if (nb) {
-        std::vector<uint16_t> b(nb, 0);
-        memcpy(b.data(), ix.start.data(), ix.nbuckets * sizeof(uint16_t));
-        HIPCHK(c, hipMalloc(&c->d_bucket, nb * sizeof(uint16_t)));
-        HIPCHK(c, hipMemcpy(c->d_bucket, b.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
     if (c->tix.ok) {
         std::vector<uint32_t> r((c->tix.rec.size() + 3) & ~(size_t)3, 0u);
         memcpy(r.data(), c->tix.rec.data(), c->tix.rec.size() * sizeof(uint32_t));
@@ -262,23 +239,14 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     }
     QuantDev &q = c->q;
     q.lut = c->d_lut;
-    q.bucket = c->d_bucket;
     q.rec = c->d_rec;
     q.lut_len = (int)n;
     q.pad = (int)(lut_floats - n);
     q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
     q.mode = mode;
-    if (c->tix.ok) {
-        q.shift = c->tix.shift;
-        q.kmin = c->tix.kmin;
-        q.nbuckets = c->tix.nbuckets;
-        q.steps = 0;
-    } else {
-        q.shift = ix.shift;
-        q.kmin = ix.kmin;
-        q.nbuckets = ix.nbuckets;
-        q.steps = ix.steps;
-    }
+    q.shift = c->tix.ok ? c->tix.shift : 0;
+    q.kmin = c->tix.ok ? c->tix.kmin : 0;
+    q.nbuckets = c->tix.ok ? c->tix.nbuckets : 0;
     q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);        // src/luma_quantizer.cpp:183
     q.cs = cs;
     q.Lmax = maxLum;
@@ -288,25 +256,6 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     c->minLum = minLum;
     c->have_quant = true;
     return LUMAHIP_OK;
-}
-
-// host-only view of the search index (no GPU, no context): what lumahip_set_quantizer would build for this table
-extern "C" int lumahip_lut_index_host(const float *lut, size_t n, int info[5], uint16_t *start_out, size_t start_cap)
-{
-    if (!lut || !info || n < 2 || n > 65536)
-        return LUMAHIP_ERR_ARG;
-    const LutIndex ix = build_lut_index(lut, (int)n);
-    info[0] = ix.mode;
-    info[1] = ix.shift;
-    info[2] = ix.kmin;
-    info[3] = ix.steps;
-    info[4] = ix.nbuckets;
-    if (start_out) {
-        if (start_cap < ix.start.size())
-            return LUMAHIP_ERR_ARG;
-        memcpy(start_out, ix.start.data(), ix.start.size() * sizeof(uint16_t));
-    }
-    return (int)ix.start.size() >= 0 ? LUMAHIP_OK : LUMAHIP_ERR_ARG;
 }
 
 // host-only view of the threshold records (no GPU, no context): info = {ok, mant_bits, shift, kmin, nbuckets}
@@ -335,10 +284,8 @@ static size_t lds_bytes(const lumahip_ctx *c, bool encode_side)
     size_t b = 0;
     const size_t lut_b = ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
     if (encode_side) {
-        if (q.mode == LUT_LITERAL_LDS || q.mode == LUT_BUCKET_LDS)
+        if (q.mode == LUT_LITERAL_LDS)
             b += lut_b;
-        if (q.mode == LUT_BUCKET_LDS)
-            b += ((size_t)q.nbuckets * 2 + 15) & ~(size_t)15;
         if (q.mode == LUT_THRESH_LDS)
             b += ((size_t)q.nbuckets * 4 + 15) & ~(size_t)15;
     } else if (c->lut_in_lds) {
@@ -371,9 +318,9 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
     if (!c->have_quant)
         return LUMAHIP_ERR_STATE;
     info[0] = c->q.mode;
-    info[1] = c->tix.ok ? c->tix.mant_bits : c->idx.mant_bits;
+    info[1] = c->tix.ok ? c->tix.mant_bits : 0;
     info[2] = c->q.nbuckets;
-    info[3] = c->q.steps;
+    info[3] = c->tix.ok ? c->tix.shift : 0;
     info[4] = (int)lds_bytes(c, true);
     return LUMAHIP_OK;
 }
@@ -384,32 +331,25 @@ typedef void (*enc_kernel_t)(const EncArgs);
 typedef void (*dec_kernel_t)(const DecArgs);
 
 template <int CS, bool SUB>
-static enc_kernel_t pick_enc2(int vw, int mode, int steps)
+static enc_kernel_t pick_enc2(int vw, int mode)
 {
     if (mode == LUT_THRESH_LDS)
         return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
     if (mode == LUT_THRESH_GLOBAL)
         return vw == 4 ? k_encode<CS, SUB, 4, 4> : k_encode<CS, SUB, 2, 4>;
-    if (mode == LUT_BUCKET_LDS) {
-        if (vw == 4 && steps == 1)
-            return k_encode<CS, SUB, 4, 11>;
-        if (vw == 4 && steps == 2)
-            return k_encode<CS, SUB, 4, 12>;
-        return vw == 4 ? k_encode<CS, SUB, 4, 1> : k_encode<CS, SUB, 2, 1>;
-    }
     if (mode == LUT_LITERAL_LDS)
         return k_encode<CS, SUB, 2, 0>;
     return k_encode<CS, SUB, 2, 2>;
 }
 
-static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode, int steps)
+static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
 {
     switch (cs) {
-    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode, steps) : pick_enc2<CS_LUV, false>(vw, mode, steps);
-    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode, steps) : pick_enc2<CS_RGB, false>(vw, mode, steps);
-    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode, steps) : pick_enc2<CS_YCBCR, false>(vw, mode, steps);
-    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode, steps) : pick_enc2<CS_XYZ, false>(vw, mode, steps);
-    case CS_PACK: return sub ? pick_enc2<CS_PACK, true>(vw, mode, steps) : pick_enc2<CS_PACK, false>(vw, mode, steps);
+    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode) : pick_enc2<CS_LUV, false>(vw, mode);
+    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode) : pick_enc2<CS_RGB, false>(vw, mode);
+    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode) : pick_enc2<CS_YCBCR, false>(vw, mode);
+    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode) : pick_enc2<CS_XYZ, false>(vw, mode);
+    case CS_PACK: return sub ? pick_enc2<CS_PACK, true>(vw, mode) : pick_enc2<CS_PACK, false>(vw, mode);
     }
     return nullptr;
 }
@@ -508,7 +448,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
     const int mode = c->q.mode;
-    const bool fast_search = (mode == LUT_BUCKET_LDS || mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
+    const bool fast_search = (mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
     int vw = (fast_search && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
@@ -536,7 +476,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     }
     const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
-    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode, c->q.steps);
+    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles);
@@ -1152,7 +1092,6 @@ static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t 
         void (*kern)(const QArrArgs) = k_quantize_array<2>;
         switch (c->q.mode) {
         case LUT_LITERAL_LDS: kern = k_quantize_array<0>; break;
-        case LUT_BUCKET_LDS: kern = k_quantize_array<1>; break;
         case LUT_THRESH_LDS: kern = k_quantize_array<3>; break;
         case LUT_THRESH_GLOBAL: kern = k_quantize_array<4>; break;
         default: break;
@@ -1224,7 +1163,7 @@ extern "C" int lumahip_powf_probe_device(lumahip_ctx *c, float *out_dev, uint32_
     return LUMAHIP_OK;
 }
 
-extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, uint32_t first_bits, size_t n, int posnan)
+extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg)
 {
     if (!c || !out_dev || n == 0 || (n % 4) != 0 || !is_aligned(out_dev, 8))
         return fail(c, LUMAHIP_ERR_ARG, "bad argument (n must be a multiple of 4, out 8-byte aligned)");
@@ -1237,18 +1176,10 @@ extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, 
     c->cs_override = cs_saved;
     void (*kern)(const QuantDev, uint16_t *, uint32_t, size_t) = nullptr;
     switch (c->q.mode) {
-    case LUT_LITERAL_LDS: kern = posnan ? k_quantize_probe<0, true> : k_quantize_probe<0, false>; break;
-    case LUT_LITERAL_GLOBAL: kern = posnan ? k_quantize_probe<2, true> : k_quantize_probe<2, false>; break;
-    case LUT_BUCKET_LDS:
-        if (c->q.steps == 1)
-            kern = posnan ? k_quantize_probe<11, true> : k_quantize_probe<11, false>;
-        else if (c->q.steps == 2)
-            kern = posnan ? k_quantize_probe<12, true> : k_quantize_probe<12, false>;
-        else
-            kern = posnan ? k_quantize_probe<1, true> : k_quantize_probe<1, false>;
-        break;
-    case LUT_THRESH_LDS: kern = posnan ? k_quantize_probe<3, true> : k_quantize_probe<3, false>; break;
-    case LUT_THRESH_GLOBAL: kern = posnan ? k_quantize_probe<4, true> : k_quantize_probe<4, false>; break;
+    case LUT_LITERAL_LDS: kern = nonneg ? k_quantize_probe<0, true> : k_quantize_probe<0, false>; break;
+    case LUT_LITERAL_GLOBAL: kern = nonneg ? k_quantize_probe<2, true> : k_quantize_probe<2, false>; break;
+    case LUT_THRESH_LDS: kern = nonneg ? k_quantize_probe<3, true> : k_quantize_probe<3, false>; break;
+    case LUT_THRESH_GLOBAL: kern = nonneg ? k_quantize_probe<4, true> : k_quantize_probe<4, false>; break;
     }
     if (!kern)
         return fail(c, LUMAHIP_ERR_STATE, "unknown search mode %d", c->q.mode);

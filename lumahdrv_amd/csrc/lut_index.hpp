@@ -1,18 +1,11 @@
-// lut_index.hpp -- host-side construction of the bucketed LUT search index.
+// lut_index.hpp -- host-side construction of the luminance search index ("threshold records").
 //
 // The reference quantizes a luminance by bisection over the whole transfer-function table
 // (LumaQuantizer::quantize, src/luma_quantizer.cpp:222-235): l=0, r=maxVal, halve until r==l+1, then
-// pick the nearer of map[l], map[r] by two rounded fp32 subtractions.  For a table that is
-// non-decreasing and NaN-free the loop's result is a pure function of v:
-//
-//      l = clamp( (number of entries <= v) - 1, 0, maxVal-1 ),   r = l + 1
-//
-// (invariant map[l] <= v < map[r] with the two ends never tested).  The kernels exploit that: the top
-// bits of v's IEEE-754 encoding (exponent + B mantissa bits) select a bucket whose first entry index
-// start[k] was precomputed here; the bucket spans at most 2^S-1 further entries, so S compare-and-step
-// probes (instead of log2(2^bits) = 10..12) reach the same l, and the final nearest-of-two decision is
-// then evaluated literally.  Tables that are not monotone (possible when a decoder is handed an
-// arbitrary attachment-434 table) get mode LITERAL and the kernels run the reference's bisection as is.
+// pick the nearer of map[l], map[r] by two rounded fp32 subtractions.  The kernels replace that by ONE
+// 4-byte gather per value (below).  Tables that do not qualify (NaNs, decreasing entries -- possible when a
+// decoder is handed an arbitrary attachment-434 table) get mode LITERAL and the kernels run the reference's
+// bisection as is.
 #pragma once
 
 #include <cstdint>
@@ -22,21 +15,9 @@ namespace lh {
 
 enum LutMode : int {
     LUT_LITERAL_LDS = 0,    // reference bisection, table staged in LDS
-    LUT_BUCKET_LDS = 1,     // bucketed search, table + bucket starts staged in LDS
     LUT_LITERAL_GLOBAL = 2, // reference bisection on the table in global memory (bitdepth > 12)
-    LUT_THRESH_LDS = 3,     // threshold records (below), staged in LDS: ONE 4-byte LDS read per value
+    LUT_THRESH_LDS = 3,     // threshold records staged in LDS: ONE 4-byte LDS read per value
     LUT_THRESH_GLOBAL = 4   // threshold records in global memory / L2 (record table too large for LDS)
-};
-
-struct LutIndex {
-    int mode = LUT_LITERAL_LDS;
-    int mant_bits = 0;  // B
-    int shift = 0;      // 23 - B
-    int kmin = 0;       // key of bucket 0
-    int nbuckets = 0;   // K
-    int steps = 0;      // S
-    int pad = 1;        // NaN floats appended after the table: probes reach index maxVal + 2^S
-    std::vector<uint16_t> start;  // K entries: BYTE offset (4 * first candidate index) per bucket
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -58,7 +39,8 @@ struct LutIndex {
 // -- the carry out of the low field is the "v >= T" test.  Bucket kmin (start c0, u 0) also receives everything
 // below it through the key clamp (negatives, -0, -inf: all code c0); the last bucket (start maxVal, u 0) receives
 // everything above the last threshold, +inf and sign-clear NaNs (the reference returns maxVal for any NaN; a
-// caller that may see a sign-set NaN tests for NaN explicitly).  tests/test_gpu_exhaustive.py compares this with
+// caller that may see negative values tests for NaN explicitly, one that cannot clamps the key as an unsigned number,
+// which sends sign-set NaNs to the top bucket as well; kmin >= 0 always).  tests/test_gpu_exhaustive.py compares this with
 // the literal bisection for all 2^32 bit patterns through the encode kernels themselves.
 struct ThreshIndex {
     bool ok = false;
@@ -74,8 +56,5 @@ int quantize_literal_host(float v, const float *lut, int maxVal);
 // device-equivalent evaluation of a record table (v must not be a sign-set NaN)
 int thresh_lookup_host(const ThreshIndex &ix, float v);
 ThreshIndex build_thresh_index(const float *lut, int n, int max_buckets);
-
-// lut has n = maxVal+1 entries
-LutIndex build_lut_index(const float *lut, int n, int max_lds_bitdepth = 12);
 
 }  // namespace lh

@@ -7,8 +7,9 @@
      a. the array kernel k_quantize_array (public LumaQuantizer::quantize over arrays; N = 1, explicit NaN test);
      b. the ENCODE KERNEL ITSELF, k_encode<CS_RGB, 4:4:4, VW=4, records> (profile 3; RGB hands raw floats to the
         search for all three planes; N = 4 and N = 8 call shapes, explicit NaN test);
-     c. quantize_lut<records, 4, POSNAN=true>, the instantiation the Lu'v' encode kernels call (they promise the
-        search a sign-clear NaN), over 0 .. 0x7fffffff = every non-negative float, +inf and every sign-clear NaN.
+     c. quantize_lut<records, 4, NONNEG=true>, the instantiation the Lu'v' encode kernels call (they promise the
+        search "v >= 0 or NaN"), over 0 .. 0x7fffffff = every non-negative float, +inf and every sign-clear NaN, plus
+        every sign-set NaN 0xff800001 .. 0xffffffff.
    The other side of each comparison is the literal bisection kernel on the GPU (LUMAHIP_FORCE_LITERAL), itself
    pinned against the oracle / the reference fixtures in test_gpu_parity.py and spot-checked here against the oracle.
 2. The device powf (pow_glibc.hpp) equals the host libm powf for every non-negative float, for the four PQ exponents.
@@ -27,7 +28,6 @@ def _pair(L, ptf, bits, cs):
     """(records context, literal context) for the same table"""
     lut = L.build_lut(ptf, bits, 1e4, 0.005)
     os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
-    os.environ.pop("LUMAHIP_SEARCH", None)
     fast = L.Context(0)
     fast.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
     assert fast.quantizer_info()["mode"] in (3, 4)
@@ -175,9 +175,9 @@ def test_global_memory_records_sampled(oracle_mod, ptf, bits):
 
 
 @pytest.mark.parametrize("ptf,bits", TABLES)
-def test_luv_kernel_search_variant_for_every_nonnegative_float_and_positive_nan(oracle_mod, ptf, bits):
-    """(c): quantize_lut<records, 4, POSNAN=true> -- what k_encode<CS_LUV, ...> calls for a row of luminances -- over
-    every bit pattern 0 .. 0x7fffffff, against the literal kernel's POSNAN=false instantiation."""
+def test_luv_kernel_search_variant_for_every_nonnegative_float_and_every_nan(oracle_mod, ptf, bits):
+    """(c): quantize_lut<records, 4, NONNEG=true> -- what k_encode<CS_LUV, ...> calls for a row of luminances -- over
+    every bit pattern 0 .. 0x7fffffff and every sign-set NaN, against the literal kernel's general instantiation."""
     import torch
     import lumahdrv_amd as L
     dev = torch.device("cuda:0")
@@ -190,14 +190,19 @@ def test_luv_kernel_search_variant_for_every_nonnegative_float_and_positive_nan(
     b = torch.empty(n, dtype=torch.int16, device=dev)
     bad = 0
     for chunk in range(8):
-        fast.quantize_probe_device(a.data_ptr(), chunk * n, n, posnan=True)
-        lit.quantize_probe_device(b.data_ptr(), chunk * n, n, posnan=False)
+        fast.quantize_probe_device(a.data_ptr(), chunk * n, n, nonneg=True)
+        lit.quantize_probe_device(b.data_ptr(), chunk * n, n, nonneg=False)
         bad += int((a != b).sum().item())
     assert bad == 0
-    # and the non-POSNAN instantiation of the same shape on the negative half, sampled
+    # sign-set NaNs: 0xff800001 .. 0xffffffff (start at 0xff800004 to keep the 4-value groups aligned, the first three
+    # are covered by the general sweep of the other tests) -- all must give maxVal
+    m = (1 << 32) - 0xff800004
+    fast.quantize_probe_device(a.data_ptr(), 0xff800004, m, nonneg=True)
+    assert bool((a[:m] == ((1 << bits) - 1)).all().item())
+    # and the general instantiation of the same shape on the negative half, sampled
     for chunk in (8, 11, 15):
-        fast.quantize_probe_device(a.data_ptr(), chunk * n, 1 << 24, posnan=False)
-        lit.quantize_probe_device(b.data_ptr(), chunk * n, 1 << 24, posnan=False)
+        fast.quantize_probe_device(a.data_ptr(), chunk * n, 1 << 24, nonneg=False)
+        lit.quantize_probe_device(b.data_ptr(), chunk * n, 1 << 24, nonneg=False)
         bad += int((a[:1 << 24] != b[:1 << 24]).sum().item())
     assert bad == 0
     fast.set_stream(None)

@@ -69,46 +69,6 @@ def test_plane_geometry_matches_vpx_img_alloc():
     assert plane_geometry(250, 100, 3)[2] == (512, 512, 512)
 
 
-def test_lut_search_index_is_sound(L, golden_dir):
-    """The host-built bucket index (lut_index.cpp) against a numpy emulation of the device search
-    (quantize_lut_bucket): for dense samples of v the bucket start plus at most 2^S-1 further entries must reach
-    l = clamp(#{entries <= v} - 1, 0, maxVal-1), the closed form of the reference's bisection
-    (src/luma_quantizer.cpp:222-231) for a monotone table."""
-    from lumahdrv_amd import capi
-    from tests.golden.make_golden import CONFIGS
-    g = np.load(os.path.join(golden_dir, "ref_luts.npz"))
-    rng = np.random.default_rng(0)
-    for name in CONFIGS:
-        m = g[name]
-        ix = capi.lut_index(m)
-        assert ix["mode"] == 1 and ix["steps"] <= 3, name
-        maxVal = m.size - 1
-        v = np.concatenate([m, np.nextafter(m, np.float32(np.inf)), np.nextafter(m, np.float32(-np.inf)),
-                            np.exp(rng.uniform(np.log(1e-7), np.log(1e6), 200000)).astype(np.float32),
-                            np.array([0.0, -1.0, 1e-45, 3e38, np.inf, -np.inf], dtype=np.float32)])
-        bits = v.view(np.int32).astype(np.int64)
-        nb = ix["nbuckets"]
-        assert ix["start"][nb - 1] == 4 * maxVal               # the "above the whole table" bucket
-        k = np.clip((bits >> ix["shift"]) - ix["kmin"], 0, nb - 1)   # the device's v_med3_i32 on the raw key
-        l = ix["start"][k].astype(np.int64) // 4
-        mp = np.concatenate([m, np.full(2 ** ix["steps"] + 1, np.nan, dtype=np.float32)])
-        for s in range(ix["steps"] - 1, -1, -1):
-            c = l + (1 << s)
-            with np.errstate(invalid="ignore"):
-                l = np.where(mp[c] <= v, c, l)
-        expect = np.clip(np.searchsorted(m, v, side="right") - 1, 0, None)     # unclamped at the top, as the kernel
-        assert np.array_equal(l, np.minimum(expect, maxVal)), name
-        assert nb <= 8192
-    # tables the closed form does not cover fall back to the literal bisection
-    bad = g["pq11_luv8"].copy()
-    bad[100], bad[101] = bad[101], bad[100]
-    assert capi.lut_index(bad)["mode"] == 0
-    nanlut = g["pq11_luv8"].copy()
-    nanlut[7] = np.nan
-    assert capi.lut_index(nanlut)["mode"] == 0
-    assert capi.lut_index(L.build_lut(L.PTF_PQ, 13))["mode"] == 2
-
-
 def _records_vs_oracle(capi, o, m, orc, rng):
     ix = capi.thresh_index(m)
     assert ix["ok"]

@@ -41,8 +41,8 @@ def main():
             me = sorted(ctx.time_launches(0, 1, src.data_ptr(), n3, B, w, h, 1.0, profile, pl, st, psz) for _ in range(5))[2]
             md = sorted(ctx.time_launches(1, 1, out.data_ptr(), n3, B, w, h, 1.0, profile, pl, st, psz) for _ in range(5))[2]
             px = B * w * h
-            rows.append("ptf %d bits %2d %-6s profile %d  search mode %d steps %d : encode %7.1f Gpx/s  decode %7.1f Gpx/s"
-                        % (ptf, bits, names[cs], profile, info["mode"], info["steps"], px / me / 1e6, px / md / 1e6))
+            rows.append("ptf %d bits %2d %-6s profile %d  search mode %d : encode %7.1f Gpx/s  decode %7.1f Gpx/s"
+                        % (ptf, bits, names[cs], profile, info["mode"], px / me / 1e6, px / md / 1e6))
             print(rows[-1], flush=True)
         ctx.close()
     # 8-bit profiles with an 8-bit table
