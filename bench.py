@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the HDR quantize hot path (4K PQ 11-bit Lu'v', VP9 profile 2) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: re-launches itself under
+                                                             torch.distributed.run with N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the fused encode kernel (RGB -> XYZ -> Lu'v' -> PQ-LUT quantize -> 4:2:0 16-bit
-planes, = LumaEncoder::encode minus the VP9 stage) over one batch of `--frames-per-step` synthetic
-3840x2160 frames that are already resident in HBM.  The default K=25 steps x 20 frames is BASELINE.json
-configs[1]'s 500-frame stream; every step reads frames no earlier step touched (a ring of distinct
-batches when memory is short), so nothing is served from L2 / Infinity Cache.  W warm-up steps, then exactly K
-steps between barrier + synchronize, MAX over ranks; rank 0 prints ONE JSON line.
+A *step* is one pass of the fused encode kernel (RGB -> XYZ -> Lu'v' -> PQ quantize -> 4:2:0 16-bit planes,
+= LumaEncoder::encode minus the VP9 stage) over one batch of `--frames-per-step` synthetic 3840x2160 frames that
+are already resident in HBM.  The resident stream is BASELINE.json configs[1]'s 500 frames (25 batches of 20;
+fewer when memory is short); steps walk it cyclically, so every step reads 2 GB that the previous ~24 steps evicted
+from L2 / Infinity Cache.  W warm-up steps, then EXACTLY K steps between barrier + synchronize, MAX over ranks.  That
+K-step region is repeated until >= --min-seconds of device time has been spent (sustained clocks, not a burst);
+`ms_per_step` / `value` are the MEDIAN region, min / max are reported next to it.  Rank 0 prints ONE JSON line.
 
-Multi-GPU: frames are independent, so rank r owns frame indices [r*K*B, (r+1)*K*B) (weak scaling, no
-data-path collective); the only communication is one RCCL broadcast of the transfer-function table and the
-quantizer parameters from rank 0 before the timed region.
+Multi-GPU: frames are independent, so rank r owns its own block of frame indices (weak scaling, no data-path
+collective); the only communication is one RCCL broadcast of the transfer-function table and the quantizer
+parameters from rank 0 before the timed region.  `--stream-frames F` switches to BASELINE configs[4]'s mode: ONE
+F-frame stream (default use: 2000) block-sharded over the ranks (250 per GPU at N = 8, strong scaling), per-frame
+plane digests all_gathered in stream order and spot-checked by rank 0.
 
-Extra legs reported in the same line (not part of `value`): decode and encode+decode round trip, the
-roofline of the encode kernel (HIP events on the launch stream, live), and the CPU oracle timed on this
-host (`cpu_baseline`).
+Extra fields in the same line (not part of `value`): decode and encode+decode round trip, the roofline of the encode
+kernel (HIP events on the launch stream, live), `other_workloads` (BASELINE configs[2] HDR10/YCbCr at 4K and configs[3]
+LOG-12 at 7680x4320, each with its own roofline block; N = 1 only) and the CPU reference timed on this host
+(`cpu_baseline`, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,69 +42,264 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 W4K, H4K = 3840, 2160
+W8K, H8K = 7680, 4320
 SEED = 20250929
 BYTES_PER_PIXEL = 15.0      # 12 B read (3 x fp32) + 3 B written (Y 2 B + U 0.5 B + V 0.5 B), SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip-level parameters)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--steps", type=int, default=25, help="steps per timed region (default 25 = one pass over the 500-frame stream)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=20)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--workload", default="pq11_luv", choices=["pq11_luv", "pq10_ycbcr", "log12_luv"])
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the K-step timed region until this much device time has been measured (per leg)")
+    ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--stream-frames", type=int, default=0,
+                    help="BASELINE configs[4] mode: ONE stream of this many frames (2000) block-sharded over the ranks")
+    ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="per-launch HBM bytes from the rocprofv3 PMC passes (tools/profile_round.sh + tools/summarize_profile.py); optional")
+    ap.add_argument("--profile-dir", default=os.path.join(ROOT, "profiles"),
+                    help="where traffic_latest.json / valu_mix_latest.json (tools/summarize_profile.py) live")
     return ap.parse_args()
 
 
 WORKLOADS = {
-    # name: (ptf, bits, cs, bitsC, maxLum, minLum, preScaling, profile, description)
+    # name: (ptf, bits, cs, bitsC, maxLum, minLum, preScaling, profile, description, transform, kernel)
     "pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0, 2, "PQ 11-bit Lu'v' 8-bit chroma, profile 2 (4:2:0 16-bit)",
                  "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
     "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0, 2, "HDR10 recipe: PQ 10-bit YCbCr BT.2020 10-bit chroma, max/min 1000/0.01, preScaling 20",
-                   "RGB->PQ->Y'CbCr (8 glibc-exact powf per pixel: fp64-VALU-bound, not HBM-bound)",
+                   "RGB->PQ->Y'CbCr (8 glibc-exact powf per pixel: VALU-bound, not HBM-bound)",
                    "lh::k_encode<CS_YCBCR,4:2:0,VW=4,LDS threshold records>"),
     "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0, 2, "LOG 12-bit Lu'v' 8-bit chroma, profile 2",
                   "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
 }
 
 
-def main():
-    args = parse()
-    # The contract is ONE JSON line on stdout.  Libraries (RCCL with NCCL_DEBUG=VERSION, the ROCm runtime) print
-    # banners to the C-level stdout, flushed at exit -- i.e. after anything Python prints.  So file descriptor 1 is
-    # pointed at stderr for the whole run and the JSON line is written to the saved real stdout at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # LUMAHIP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all_reduce) with one rank too
-    use_dist = world > 1 or os.environ.get("LUMAHIP_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
-    n_gpus = world
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    import lumahdrv_amd as L   # after torch: one HIP runtime in the process
 
-    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[args.workload]
-    w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
+def respawn(args):
+    """`python bench.py --gpus N` with no launcher environment: run the same command line under torch.distributed.run,
+    one rank per GPU, and pass its single JSON line through."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices"
+                         % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    # ---- quantizer: rank 0 builds the table on its host, RCCL-broadcasts it and the parameters over xGMI
+
+class Timer:
+    """W warm-up steps, then EXACTLY K steps between barrier + synchronize, wall-clock MAX over ranks; that K-step region
+    is repeated (warm-up only before the first) until min_seconds of device time is accumulated.  The kernels run on
+    torch's current stream (ctx.set_stream), so the torch.cuda.Event pair around the K launches is a hipEvent pair on the
+    launch stream: `dev_ms` = device time of each region."""
+
+    def __init__(self, K, Wm, use_dist, dev, min_seconds, max_repeats):
+        self.K, self.Wm, self.use_dist, self.dev = K, Wm, use_dist, dev
+        self.min_seconds, self.max_repeats = min_seconds, max_repeats
+
+    def region(self, fn, first):
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(self.K):
+            fn(first + i)
+        e1.record()
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    def run(self, fn):
+        for i in range(self.Wm):
+            fn(i)
+        walls, devs = [], []
+        step = self.Wm
+        while True:
+            wall, dev_ms = self.region(fn, step)
+            step += self.K
+            walls.append(wall)
+            devs.append(dev_ms)
+            # every rank must take the same decision: rank 0 decides
+            more = torch.tensor([1 if (sum(devs) * 1e-3 < self.min_seconds and len(devs) < self.max_repeats) else 0],
+                                dtype=torch.int32, device=self.dev)
+            if self.use_dist:
+                dist.broadcast(more, src=0)
+            if int(more.item()) == 0:
+                break
+        t = torch.tensor(walls, dtype=torch.float64, device=self.dev)
+        if self.use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per region: the slowest rank
+        walls = t.cpu().numpy()
+        return {"wall_median": float(np.median(walls)), "wall_min": float(walls.min()), "wall_max": float(walls.max()),
+                "dev_ms_median": float(np.median(devs)), "repeats": len(devs), "seconds": float(walls.sum())}
+
+
+def load_profile(path, workload, px_step, sha):
+    """a committed rocprofv3-derived figure is only reported when it was captured from THESE kernel sources"""
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+        ent = tj.get(workload) if workload in tj else tj
+        if ent.get("kernel_source_sha") == sha and ent.get("workload", workload) == workload:
+            return ent
+    except Exception:
+        pass
+    return None
+
+
+def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha):
+    """one workload: resident synthetic stream, encode timed (plus decode / round trip for the main one), roofline block"""
     from lumahdrv_amd.sharding import broadcast_quantizer
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
+    cfg0 = lut0 = None
+    if rank == 0:   # rank 0 builds the table on its host; RCCL broadcast of table + parameters over xGMI
+        cfg0 = (ptf, bits, cs, bitsC, maxLum, minLum, sc, profile)
+        lut0 = L.build_lut(ptf, bits, maxLum, minLum)
+    cfg, lut = broadcast_quantizer(cfg0, lut0, dev)
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile = cfg
+    ctx = L.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_quantizer(ptf, bits, cs, bitsC, maxLum, minLum, lut)
+
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    per_frame = n3 * 4 * (2 if main else 1) + sum(psz)     # input (+ decoded output) + planes
+    free, _total = torch.cuda.mem_get_info(dev)
+    want_frames = 500 if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)    # >= 4 GB of distinct input: >> 256 MB MALL
+    nbatch = max(1, min(want_frames // B, int(free * 0.8 // per_frame) // B))
+    nfr = nbatch * B
+    src = torch.empty(nfr * n3, dtype=torch.float32, device=dev)
+    out = torch.empty(nfr * n3 if main else 0, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(nfr * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    first = rank * nfr                                     # each rank has its own stream (weak scaling)
+    for b in range(nbatch):
+        ctx.synth_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, SEED, first + b * B)
+    torch.cuda.synchronize()
+
+    def ptrs(b):
+        return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4 if main else 0,
+                [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
+
+    def enc(i):
+        s, _, pl = ptrs(i % nbatch)
+        ctx.encode_frames_device(s, n3, B, w, h, sc, profile, pl, st, psz)
+
+    def dec(i):
+        _, o, pl = ptrs(i % nbatch)
+        ctx.decode_frames_device(pl, st, psz, B, w, h, profile, sc, o, n3)
+
+    tm = Timer(K, Wm, use_dist, dev, args.min_seconds, args.max_repeats)
+    px_step = float(B) * w * h
+    te = tm.run(enc)
+
+    def rate(t):
+        return world * K * px_step / t / 1e6
+
+    r = {"value": round(rate(te["wall_median"]), 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * te["wall_median"] / K, 4),
+         "ms_per_step_min": round(1e3 * te["wall_min"] / K, 4), "ms_per_step_max": round(1e3 * te["wall_max"] / K, 4),
+         "repeats": te["repeats"], "timed_seconds": round(te["seconds"], 3),
+         "workload": "%dx%d %s encode (%s, LUT quantize, 4:2:0 16-bit pack), %d frames/step, %d-frame resident stream per GPU"
+                     % (w, h, desc, xf_desc, B, nfr),
+         "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
+         "distinct_input_GB_per_gpu": round(nfr * n3 * 4 / 1e9, 2)}
+    if main:
+        td = tm.run(dec)
+        trt = tm.run(lambda i: (enc(i), dec(i)))
+        r["decode_mpix_s"] = round(rate(td["wall_median"]), 1)
+        r["roundtrip_mpix_s"] = round(rate(trt["wall_median"]), 1)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: hipEvents over the timed regions (median region / K), rank 0
+        avg_ms = te["dev_ms_median"] / K
+        iso = [ctx.time_launches(0, 1, ptrs(i % nbatch)[0], n3, B, w, h, sc, profile, ptrs(i % nbatch)[2], st, psz)
+               for i in range(max(5, min(25, nbatch)))]
+        achieved = BYTES_PER_PIXEL * px_step / (avg_ms * 1e-3) / 1e9
+        hbm = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+               "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step}
+        probe_ms = None
+        if profile == 2 and w % 4 == 0:
+            # the same loads and stores with no arithmetic: what the memory system gives this traffic mix on THIS box.
+            # (overwrites the planes of these batches with garbage; nothing reads them afterwards)
+            probe_ms = float(np.median([ctx.probe_encode_traffic(ptrs(i % nbatch)[0], n3, B, w, h, ptrs(i % nbatch)[2], st, psz)
+                                        for i in range(max(5, min(25, nbatch)))]))
+        tr = load_profile(os.path.join(args.profile_dir, "traffic_latest.json"), name, px_step, sha)
+        common = {"kernel": kname, "kernel_ms": round(avg_ms, 4), "kernel_ms_isolated_launch": round(float(np.median(iso)), 4),
+                  "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                  "traffic_source": ("rocprofv3 PMC passes of tools/profile_round.sh (2 x FETCH_SIZE + WRITE_SIZE), captured "
+                                     "from these kernel sources at commit %s: %s" % (tr.get("commit", "?"), tr.get("tag", "?")))
+                                    if tr else "no PMC capture of the current kernel sources in profiles/ (null, not a stale figure)",
+                  "traffic_only_ms": None if probe_ms is None else round(probe_ms, 4),
+                  "frac_of_traffic_only_rate": None if probe_ms is None else round(probe_ms / avg_ms, 3)}
+        mix = load_profile(os.path.join(args.profile_dir, "valu_mix_latest.json"), name, px_step, sha)
+        if cs == 2:
+            # YCbCr: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
+            # issue cost measured by tools/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
+            # conversions / compares / selects / min / max 4, transcendental 8); peak = every SIMD issuing every cycle.
+            peak = N_SIMD * CLOCK_GHZ                                  # G SIMD-cycles / s
+            if mix:
+                cyc = mix["issue_cycles_per_launch"] * (px_step / mix["pixels_per_launch"])   # SIMD-cycles of VALU issue
+                ach = cyc / (avg_ms * 1e-3) / 1e9                      # G SIMD-cycles / s actually spent issuing VALU
+                r["roofline"] = dict({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
+                                      "unit": "G SIMD-issue-cycles/s", "frac": round(ach / peak, 4),
+                                      "valu_instructions_per_pixel": mix.get("valu_per_pixel"),
+                                      "fp64_instructions_per_pixel": mix.get("fp64_per_pixel"), "hbm": hbm}, **common)
+            else:
+                r["roofline"] = dict({"bound": "valu", "achieved": None, "peak": round(peak, 1), "unit": "G SIMD-issue-cycles/s",
+                                      "frac": None, "note": "no instruction-mix capture of the current kernel sources in profiles/",
+                                      "hbm": hbm}, **common)
+        else:
+            r["roofline"] = dict(dict({"bound": "hbm"}, **hbm), **common)
+            if main:
+                r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
+    ctx.close()
+    del src, out, planes
+    torch.cuda.empty_cache()
+    return r, cfg
+
+
+def frame_digests(planes, psz, nfr, dev):
+    """one int64 per frame over its three planes (position-weighted sums of the 8-byte words)"""
+    d = torch.zeros(nfr, dtype=torch.int64, device=dev)
+    for p in range(3):
+        v = planes[p][:nfr * psz[p]].view(nfr, psz[p])
+        words = v.view(torch.int64) if psz[p] % 8 == 0 else v.to(torch.int64)
+        wgt = (torch.arange(words.shape[1], dtype=torch.int64, device=dev) % 1000003) * 2 + 1
+        for f0 in range(0, nfr, 16):
+            d[f0:f0 + 16] += (words[f0:f0 + 16] * wgt).sum(dim=1) * (p + 1)
+    return d
+
+
+def run_stream(L, args, rank, world, local_rank, use_dist, dev):
+    """BASELINE configs[4]: ONE stream of F frames, block-sharded (lumahdrv_amd.sharding.shard_range: 2000 -> 250 per
+    GPU at N = 8), each rank's shard resident in its HBM; a timed region = every rank encodes its whole shard once."""
+    from lumahdrv_amd.sharding import broadcast_quantizer, gather_in_stream_order, shard_range
+    name = args.workload
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
+    w, h, B, F = args.width, args.height, args.frames_per_step, args.stream_frames
     cfg0 = lut0 = None
     if rank == 0:
         cfg0 = (ptf, bits, cs, bitsC, maxLum, minLum, sc, profile)
@@ -107,164 +309,180 @@ def main():
     ctx = L.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_quantizer(ptf, bits, cs, bitsC, maxLum, minLum, lut)
-
-    # ---- resident synthetic stream: as many distinct batches as the step count needs (or memory allows)
+    mine = shard_range(F, rank, world)
+    nfr = len(mine)
     n3 = 3 * w * h
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
-    per_frame = n3 * 4 * 2 + sum(psz)                      # input + decoded output + planes
     free, _total = torch.cuda.mem_get_info(dev)
-    max_frames = max(B, int(free * 0.8 // per_frame))
-    nbatch = max(1, min(K + Wm, max_frames // B))
-    ring_bytes = nbatch * B * n3 * 4
-    nfr = nbatch * B
-    src = torch.empty(nfr * n3, dtype=torch.float32, device=dev)
-    out = torch.empty(nfr * n3, dtype=torch.float32, device=dev)
-    planes = [torch.zeros(nfr * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
-    first = rank * (K + Wm) * B
-    for b in range(nbatch):
-        ctx.synth_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, SEED, first + b * B)
+    if (n3 * 4 + sum(psz)) * max(nfr, 1) > free * 0.9:
+        raise SystemExit("rank %d: shard of %d frames does not fit in HBM" % (rank, nfr))
+    src = torch.empty(max(nfr, 1) * n3, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(max(nfr, 1) * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    for f0 in range(0, nfr, B):
+        ctx.synth_frames_device(src.data_ptr() + f0 * n3 * 4, n3, min(B, nfr - f0), w, h, SEED, mine.start + f0)
+    steps = (nfr + B - 1) // B
+
+    def enc(i):
+        f0 = (i % max(steps, 1)) * B
+        nb = min(B, nfr - f0)
+        if nb > 0:
+            ctx.encode_frames_device(src.data_ptr() + f0 * n3 * 4, n3, nb, w, h, sc, profile,
+                                     [planes[p].data_ptr() + f0 * psz[p] for p in range(3)], st, psz)
+
+    ksteps = torch.tensor([steps], dtype=torch.int64, device=dev)
+    if use_dist:
+        dist.all_reduce(ksteps, op=dist.ReduceOp.MAX)
+    K = int(ksteps.item())                      # every rank issues K step calls (empty ones past its shard)
+    tm = Timer(K, 0, use_dist, dev, args.min_seconds, args.max_repeats)
+    enc(0)                                      # warm-up: one step
+    te = tm.run(enc)
     torch.cuda.synchronize()
-
-    def ptrs(b):
-        return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4,
-                [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
-
-    def enc(b):
-        s, _, pl = ptrs(b % nbatch)
-        ctx.encode_frames_device(s, n3, B, w, h, sc, profile, pl, st, psz)
-
-    def dec(b):
-        _, o, pl = ptrs(b % nbatch)
-        ctx.decode_frames_device(pl, st, psz, B, w, h, profile, sc, o, n3)
-
-    dev_ms = {}
-
-    def timed(fn, tag=None):
-        """W warm-up steps, then exactly K steps between barrier + synchronize; MAX over ranks (seconds).
-        The kernels run on torch's current stream (ctx.set_stream above), so a pair of torch.cuda.Events around the
-        K launches is a pair of hipEvents on the launch stream: dev_ms[tag] = device time of the timed region."""
-        for i in range(Wm):
-            fn(i)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for i in range(K):
-            fn(Wm + i)
-        e1.record()
-        torch.cuda.synchronize()
-        if tag:
-            dev_ms[tag] = e0.elapsed_time(e1)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
-    px_step = float(B) * w * h
-    t_enc = timed(enc, "enc")                                # the metric: quantize
-    t_dec = timed(dec, "dec")
-    t_rt = timed(lambda i: (enc(i), dec(i)))
-
-    value = n_gpus * K * px_step / t_enc / 1e6
-    res = {
-        "metric": "Mpixels/s HDR quantize (4K PQ Lu'v' 11-bit)" if args.workload == "pq11_luv" and (w, h) == (W4K, H4K)
-                  else "Mpixels/s HDR quantize (%s %dx%d)" % (args.workload, w, h),
-        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
-        "ms_per_step": round(1e3 * t_enc / K, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d %s encode (%s, LUT quantize, 4:2:0 16-bit pack), %d frames/step, "
-                               "%d-frame resident stream per GPU" % (w, h, desc, xf_desc, B, nfr),
-                   "timed": "the quantize (encode) pass; decode and encode+decode round trip are timed separately "
-                            "and reported as decode_mpix_s / roundtrip_mpix_s",
-                   "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
-                   "parallelism": "frame-sharded x%d" % n_gpus, "distinct_input_GB_per_gpu": round(ring_bytes / 1e9, 2)},
-        "decode_mpix_s": round(n_gpus * K * px_step / t_dec / 1e6, 1),
-        "roundtrip_mpix_s": round(n_gpus * K * px_step / t_rt / 1e6, 1),
-    }
-
-    # ---- roofline of the dominant kernel (encode): HIP events on the launch stream, live, rank 0
+    # in-order reassembly bookkeeping: per-frame digests gathered in STREAM order; rank 0 re-encodes the first and last
+    # frame of every shard itself and compares
+    dig = frame_digests(planes, psz, nfr, dev).cpu().tolist() if nfr else []
+    allv = gather_in_stream_order(dig, F, dev)
+    checked = 0
     if rank == 0:
-        s, o, pl = ptrs(0)
-        iters = max(5, min(K, nbatch))
-        # cycle over distinct batches so the working set never fits the caches
-        ms = []
-        for i in range(iters):
-            s_i, _, pl_i = ptrs(i % nbatch)
-            ms.append(ctx.time_launches(0, 1, s_i, n3, B, w, h, sc, profile, pl_i, st, psz))
-        iso_ms = float(np.mean(ms))                  # isolated launches, one hipEvent pair each
-        avg_ms = dev_ms["enc"] / K                   # hipEvents over the timed region: K back-to-back launches
-        achieved = BYTES_PER_PIXEL * px_step / (avg_ms * 1e-3) / 1e9
-        probe_ms = None
-        if profile == 2 and w % 4 == 0:
-            # the same loads and stores with no arithmetic: what the memory system gives this traffic mix here.
-            # (overwrites the planes of these batches; they are re-encoded by nothing afterwards)
-            pm = []
-            for i in range(iters):
-                s_i, _, pl_i = ptrs(i % nbatch)
-                pm.append(ctx.probe_encode_traffic(s_i, n3, B, w, h, pl_i, st, psz))
-            probe_ms = float(np.mean(pm))
-        traffic = None
-        try:
-            with open(args.traffic_json) as f:
-                tj = json.load(f)
-            if tj.get("pixels_per_launch") == px_step and tj.get("workload") == args.workload and (w, h) == (W4K, H4K):
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-        res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel": kname, "kernel_ms": round(avg_ms, 4), "kernel_ms_isolated_launch": round(iso_ms, 4),
-                           "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
-                           "traffic_only_ms": None if probe_ms is None else round(probe_ms, 4),
-                           "frac_of_traffic_only_rate": None if probe_ms is None else round(probe_ms / iso_ms, 3),
-                           "decode_achieved_GBs": round(BYTES_PER_PIXEL * px_step / (dev_ms["dec"] / K * 1e-3) / 1e9, 1)}
+        one = torch.empty(n3, dtype=torch.float32, device=dev)
+        pl1 = [torch.zeros(psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        for r in range(world):
+            rg = shard_range(F, r, world)
+            for f in sorted({rg.start, rg.stop - 1} if len(rg) else ()):
+                ctx.synth_frames_device(one.data_ptr(), n3, 1, w, h, SEED, f)
+                ctx.encode_frames_device(one.data_ptr(), n3, 1, w, h, sc, profile, [t.data_ptr() for t in pl1], st, psz)
+                torch.cuda.synchronize()
+                got = int(frame_digests(pl1, psz, 1, dev)[0].item()) & 0x7FFFFFFFFFFFFFFF
+                if got != allv[f]:
+                    raise SystemExit("stream frame %d (rank %d's shard): gathered digest differs from rank 0's re-encode" % (f, r))
+                checked += 1
+    px = float(F) * w * h
+    res = {"metric": "Mpixels/s HDR quantize (4K PQ Lu'v' 11-bit), %d-frame stream block-sharded over the GPUs" % F,
+           "value": round(px / te["wall_median"] / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": K, "warmup": 1,
+           "ms_per_step": round(1e3 * te["wall_median"] / max(K, 1), 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%dx%d %s encode, ONE %d-frame stream sharded in contiguous blocks (%d frames on rank 0), "
+                                  "%d frames/step" % (w, h, desc, F, len(shard_range(F, 0, world)), B),
+                      "frames_per_step": B, "width": w, "height": h, "parallelism": "frame-sharded x%d" % world,
+                      "world_size_reported_by": "torch.distributed (RCCL)" if use_dist else "single process"},
+           "repeats": te["repeats"], "timed_seconds": round(te["seconds"], 3),
+           "ms_per_region_min_median_max": [round(1e3 * te[k], 3) for k in ("wall_min", "wall_median", "wall_max")],
+           "digests": {"gathered_in_stream_order": len(allv), "spot_checked_by_rank0": checked,
+                       "stream_digest": "%016x" % (sum((i + 1) * v for i, v in enumerate(allv)) & 0xFFFFFFFFFFFFFFFF)}}
+    ctx.close()
+    return res
 
-    # ---- CPU baseline on this host, bounded sample.  "reference": the real LumaQuantizer of the reference
-    # (oracle/_ref/libluma_ref.so, compiled unmodified in the build container and shipped prebuilt) under the harness's
-    # plane loop, 1 thread = the reference's behaviour; falls back to "port" (oracle/luma_oracle.c) when the prebuilt
-    # reference library is absent.  The all-core figure is always the port (row-sharded over pthreads).
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        try:
-            from oracle import oracle_py as o
-            nf = max(1, args.cpu_frames)
-            cores = os.cpu_count() or 1
-            orc = o.Oracle(ptf, bits, cs, bitsC, maxLum, minLum)
-            kind, impl = "port", "oracle/luma_oracle.c (gcc -O2 -ffp-contract=off)"
-            runner = lambda f: orc.encode(f, sc, profile, threads=1)  # noqa: E731
-            if o.have_ref() and ptf in (o.PTF_PQ, o.PTF_LOG, o.PTF_LINEAR):
-                try:
-                    ref = o.RefQuantizer(ptf, bits, cs, bitsC, maxLum, minLum)
-                    if hasattr(ref.L, "ref_encode_frame"):
-                        kind, impl = "reference", ("reference LumaQuantizer (src/luma_quantizer.cpp, g++ -O2) under the "
-                                                   "plane loop of src/luma_encoder.cpp:260-317 restated in oracle/ref_harness.cpp")
-                        runner = lambda f: ref.encode(f, sc, profile)  # noqa: E731
-                except Exception:
-                    pass
-            fr = [o.synth_frame(w, h, SEED, i) for i in range(nf)]
-            t0 = time.perf_counter()
-            for f in fr:
-                runner(f)
-            t1 = time.perf_counter() - t0
-            fr = [o.synth_frame(w, h, SEED, i) for i in range(nf)]
-            t0 = time.perf_counter()
-            for f in fr:
-                orc.encode(f, sc, profile, threads=cores)
-            tn = time.perf_counter() - t0
-            res["cpu_baseline"] = {"value": round(nf * w * h / t1 / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-                                   "sample": "%d synthetic %dx%d frames, encode transform, %s, 1 thread = the reference's "
-                                             "behaviour" % (nf, w, h, impl),
-                                   "all_cores": {"value": round(nf * w * h / tn / 1e6, 2), "cores": cores, "kind": "port"}}
-        except Exception as e:  # the baseline is reporting only; never fail the bench on it
-            res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+def cpu_baseline(args, cfg, w, h):
+    """CPU reference on this host, bounded sample.  "reference": the real LumaQuantizer of the reference
+    (oracle/_ref/libluma_ref.so, compiled unmodified in the build container and shipped prebuilt) under the harness's
+    plane loop, 1 thread = the reference's behaviour; falls back to "port" (oracle/luma_oracle.c) when the prebuilt
+    reference library is absent.  The all-core figure is always the port (row-sharded over pthreads)."""
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile = cfg
+    try:
+        from oracle import oracle_py as o
+        nf = max(1, args.cpu_frames)
+        cores = os.cpu_count() or 1
+        orc = o.Oracle(ptf, bits, cs, bitsC, maxLum, minLum)
+        kind, impl = "port", "oracle/luma_oracle.c (gcc -O2 -ffp-contract=off)"
+        runner = lambda f: orc.encode(f, sc, profile, threads=1)  # noqa: E731
+        if o.have_ref() and ptf in (o.PTF_PQ, o.PTF_LOG, o.PTF_LINEAR):
+            try:
+                ref = o.RefQuantizer(ptf, bits, cs, bitsC, maxLum, minLum)
+                if hasattr(ref.L, "ref_encode_frame"):
+                    kind, impl = "reference", ("reference LumaQuantizer (src/luma_quantizer.cpp, g++ -O2) under the "
+                                               "plane loop of src/luma_encoder.cpp:260-317 restated in oracle/ref_harness.cpp")
+                    runner = lambda f: ref.encode(f, sc, profile)  # noqa: E731
+            except Exception:
+                pass
+        fr = [o.synth_frame(w, h, SEED, i) for i in range(nf)]
+        t0 = time.perf_counter()
+        for f in fr:
+            runner(f)
+        t1 = time.perf_counter() - t0
+        fr = [o.synth_frame(w, h, SEED, i) for i in range(nf)]
+        t0 = time.perf_counter()
+        for f in fr:
+            orc.encode(f, sc, profile, threads=cores)
+        tn = time.perf_counter() - t0
+        return {"value": round(nf * w * h / t1 / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                "sample": "%d synthetic %dx%d frames, encode transform, %s, 1 thread = the reference's behaviour" % (nf, w, h, impl),
+                "all_cores": {"value": round(nf * w * h / tn / 1e6, 2), "cores": cores, "kind": "port"}}
+    except Exception as e:  # the baseline is reporting only; never fail the bench on it
+        return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
+    # The contract is ONE JSON line on stdout.  Libraries (RCCL with NCCL_DEBUG=VERSION, the ROCm runtime) print
+    # banners to the C-level stdout, flushed at exit -- i.e. after anything Python prints.  So file descriptor 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d: refusing to mislabel the result" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # LUMAHIP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all_reduce) with one rank too
+    use_dist = world > 1 or os.environ.get("LUMAHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("RCCL reports world size %d, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    n_gpus = dist.get_world_size() if use_dist else 1
+
+    import lumahdrv_amd as L   # after torch: one HIP runtime in the process
+    from lumahdrv_amd import capi
+    sha = capi.kernel_source_sha()
+
+    if args.stream_frames > 0:
+        res = run_stream(L, args, rank, n_gpus, local_rank, use_dist, dev)
+    else:
+        w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
+        r, cfg = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, True, sha)
+        res = {
+            "metric": "Mpixels/s HDR quantize (4K PQ Lu'v' 11-bit)" if args.workload == "pq11_luv" and (w, h) == (W4K, H4K)
+                      else "Mpixels/s HDR quantize (%s %dx%d)" % (args.workload, w, h),
+            "value": r["value"], "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": r["workload"],
+                       "timed": "the quantize (encode) pass: K steps per region, region repeated until >= %.1f s of device time; "
+                                "value / ms_per_step = the median region; decode and encode+decode round trip are timed "
+                                "the same way and reported as decode_mpix_s / roundtrip_mpix_s" % args.min_seconds,
+                       "frames_per_step": B, "width": w, "height": h, "preScaling": r["preScaling"], "profile": r["profile"],
+                       "parallelism": "frame-sharded x%d" % n_gpus,
+                       "world_size_reported_by": "torch.distributed (RCCL)" if use_dist else "single process",
+                       "distinct_input_GB_per_gpu": r["distinct_input_GB_per_gpu"]},
+            "repeats": r["repeats"], "timed_seconds": r["timed_seconds"],
+            "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
+            "decode_mpix_s": r["decode_mpix_s"], "roundtrip_mpix_s": r["roundtrip_mpix_s"],
+            "kernel_source_sha": sha,
+        }
+        if rank == 0:
+            res["roofline"] = r["roofline"]
+        # ---- the other single-GPU configurations of BASELINE.json, same run, each with its own roofline (N = 1 only)
+        if n_gpus == 1 and not args.no_other_workloads and args.workload == "pq11_luv" and (w, h) == (W4K, H4K):
+            others = {}
+            for key, (nm, ow, oh, ob) in {"pq10_ycbcr_4k": ("pq10_ycbcr", W4K, H4K, 20),
+                                           "log12_luv_8k": ("log12_luv", W8K, H8K, 5)}.items():
+                ro, _ = run_workload(L, args, nm, ow, oh, ob, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha)
+                others[key] = ro
+            res["other_workloads"] = others
+        if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, cfg, w, h)
 
     if rank == 0:
         os.write(real_stdout, (json.dumps(res) + "\n").encode())

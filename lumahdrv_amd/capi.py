@@ -50,6 +50,17 @@ def build_library(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def kernel_source_sha() -> str:
+    """short SHA-1 over the device sources; profiles/*.json captured by rocprofv3 carry it so that bench.py never
+    reports a counter-derived figure measured on different kernels"""
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_capi.hip", "lut_index.cpp", "Makefile"):
+        with open(os.path.join(HERE, "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:12]
+
+
 _lib = None
 
 

@@ -1,0 +1,131 @@
+"""The N>1 path on real devices.  `ShardedStream` (lumahdrv_amd/sharding.py) driving a real lumahdrv_amd.Context per
+rank over the "nccl" (= RCCL) backend: 2 ranks when the box has >= 2 GPUs, 1 rank otherwise (the 1-GPU boxes still
+exercise RCCL init, the quantizer broadcast on device tensors and the digest gather).  And bench.py's own contract:
+one JSON line, the world size RCCL reports, the config-5 stream mode, and the refusal to mislabel a run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nframes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import lumahdrv_amd as L
+    from lumahdrv_amd.sharding import ShardedStream
+    from oracle import oracle_py as o          # only the synthetic frame generator and the digest function (test plumbing)
+    cfg = lut = None
+    if rank == 0:   # only rank 0 knows the configuration and builds the table
+        cfg = (L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, 1.0, 2)
+        lut = L.build_lut(L.PTF_PQ, 11, 1e4, 0.005)
+    st = ShardedStream(nframes, dev, cfg, lut)
+
+    def make_worker(cfg, lut):
+        ctx = L.Context(rank)                  # the product: HIP kernels on this rank's GPU
+        ctx.set_quantizer(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], lut)   # the BROADCAST table
+        return ctx
+
+    def process(ctx, f):
+        planes, _, _ = ctx.encode_frame(o.synth_frame(64, 32, frame=f), st.cfg[6], st.cfg[7])
+        return o.fnv1a64(np.concatenate([p.ravel() for p in planes]))
+
+    digests = st.run(make_worker, process)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(digests, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_stream_drives_real_contexts_over_rccl(tmp_path, oracle_mod):
+    import torch
+    import torch.multiprocessing as mp
+    o = oracle_mod
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    nframes = 7
+    mp.spawn(_worker, args=(world, _free_port(), nframes, str(tmp_path)), nprocs=world, join=True)
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    expect = []
+    for f in range(nframes):
+        planes, _, _ = orc.encode(o.synth_frame(64, 32, frame=f), 1.0, 2)
+        expect.append(o.fnv1a64(np.concatenate([p.ravel() for p in planes])) & 0x7FFFFFFFFFFFFFFF)
+    for r in range(world):
+        assert np.load(tmp_path / ("rank%d.npy" % r)).tolist() == expect     # every rank holds the in-order digests
+
+
+def _bench(*flags, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), capture_output=True, text=True, env=e, timeout=900)
+    return p
+
+
+@pytest.mark.gpu
+def test_bench_contract_single_gpu():
+    p = _bench("--steps", "3", "--warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-other-workloads")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["unit"] == "Mpixels/s" and r["value"] > 0
+    assert r["repeats"] >= 1 and r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
+    assert rf["traffic"] is None or abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1) < 0.05
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_and_stream_mode():
+    """the RCCL code path with the devices this box has (forced with one rank), in the 2000-frame-stream mode scaled down"""
+    import torch
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    p = _bench("--gpus", str(n), "--stream-frames", "37", "--frames-per-step", "8", "--width", "1280", "--height", "720",
+               "--min-seconds", "0.05", env={"LUMAHIP_BENCH_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert r["n_gpus"] == n and r["scaling"] == "strong"
+    assert r["digests"]["gathered_in_stream_order"] == 37 and r["digests"]["spot_checked_by_rank0"] == 2 * n
+    # the stream digest does not depend on how many ranks produced it
+    q = _bench("--gpus", "1", "--stream-frames", "37", "--frames-per-step", "5", "--width", "1280", "--height", "720",
+               "--min-seconds", "0.05")
+    assert q.returncode == 0, q.stderr[-2000:]
+    assert json.loads(q.stdout.splitlines()[-1])["digests"]["stream_digest"] == r["digests"]["stream_digest"]
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = _bench("--gpus", str(n), "--steps", "1")
+    assert p.returncode != 0 and "visible" in (p.stderr + p.stdout)
+
+
+def test_bench_never_mislabels_world_size():
+    """CPU-checkable halves of the contract: --gpus 2 with WORLD_SIZE=1 in the environment must fail (round 1 silently ran
+    one rank and printed n_gpus: 1), and --gpus 2 without devices must fail instead of reporting fewer GPUs."""
+    p = _bench("--gpus", "2", "--steps", "1", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+    import torch
+    if not torch.cuda.is_available():
+        q = _bench("--gpus", "2", "--steps", "1")
+        assert q.returncode != 0 and "visible" in (q.stderr + q.stdout)
