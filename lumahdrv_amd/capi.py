@@ -9,7 +9,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(HERE, "lib", "liblumahip.so")
+# LUMAHIP_LIB: load another build of the same ABI (A/B measurements, the -DLH_NO_FAST_DIV comparison build of the tests)
+_LIB_PATH = os.environ.get("LUMAHIP_LIB") or os.path.join(HERE, "lib", "liblumahip.so")
 
 # include/luma/luma_quantizer.h:95-96 (values are serialised in the stream metadata)
 PTF_PSI, PTF_PQ, PTF_LOG, PTF_JND_HDRVDP, PTF_LINEAR = range(5)

@@ -123,7 +123,28 @@ struct XformConst {
     float sc;               // preScaling
     float Lmax;             // PQ peak for the YCbCr path
     const PowfTables *pw;   // powf tables (LDS copy), YCbCr only
+    // refined reciprocals (rcp_nr) of the YCbCr path's constant divisors, computed once per thread instead of once
+    // per division: div_nr_r(a, b, rcp_nr(b)) is div_nr(a, b) by definition
+    float rLmax, r18814, r14746, r224, r0678;
 };
+
+template <int CS>
+LH_DEV XformConst make_xform_const(float sc, float Lmax, const PowfTables *pw)
+{
+    XformConst k;
+    k.sc = sc;
+    k.Lmax = Lmax;
+    k.pw = pw;
+    k.rLmax = k.r18814 = k.r14746 = k.r224 = k.r0678 = 0.0f;
+    if constexpr (CS == CS_YCBCR) {
+        k.rLmax = rcp_nr(Lmax);
+        k.r18814 = rcp_nr(1.8814f);
+        k.r14746 = rcp_nr(1.4746f);
+        k.r224 = rcp_nr(224.0f);
+        k.r0678 = rcp_nr(0.6780f);
+    }
+    return k;
+}
 
 // LumaQuantizer::transformPQ, src/luma_quantizer.cpp:485-501.  The constants are double literals
 // narrowed to `const float` in the reference; 1.0f/m and 1.0f/n are single fp32 divisions.
@@ -141,23 +162,53 @@ LH_DEV float pq_decode(float val, const XformConst &k)
     return k.Lmax * powf_glibc(div_ieee(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw);
 }
 
-// the same two functions on the branch-free powf; `slow` is raised when any argument left its domain
-// Divisions on the short path (div_nr): licensed for the "regular" pixel only -- val in {0} u [1e-10, FLT_MAX],
-// Lmax in [1e-6, 1e9] (checked by the caller), Lp in [4e-3, 1.3e6], Vp in [0, 1.01] with c2 - c3*Vp in [0.02, 18.9]:
-// every operand, quotient and residual is a normal float (or an exact zero).  A NaN or inf anywhere ends up as a
-// NaN argument of powf_regular, which raises `slow`, and the pixel is redone with IEEE division throughout.
-LH_DEV float pq_encode_r(float val, const XformConst &k, bool &slow)
+// The same two functions on the branch-free powf.  A SlowAcc collects, over as many pixels as the caller likes (the
+// kernels: one thread's whole unit), whether any argument left the domain in which the straight-line arithmetic
+// (powf_regular, div_nr) is licensed; the caller then redoes those pixels with the complete functions and IEEE division
+// throughout.  Two collectors, because a compare costs twice an integer max (tools/valu_bench.hip) and keeps a lane
+// mask alive in scalar registers: `umax` = running unsigned max of (bits(x) - 0x00800000) over arguments that must be
+// positive normal floats (one compare against 0x7f000000 at the end), `flag` for the tests that need their own compare.
+// Lmax in [1e-6, 1e9] is checked by the caller.
+struct SlowAcc {
+    uint32_t umax = 0;
+    bool flag = false;
+};
+LH_DEV bool slow_any(const SlowAcc &a) { return a.flag || a.umax >= 0x7f000000u; }
+
+// pq_encode_r<ANYVAL>: with ANYVAL (decode side: val is a table value, possibly 0, tiny, negative or NaN) the first
+// power tests its argument itself (ZERO, CHECK_X).  Without (encode side: val in [1e-10, FLT_MAX], or NaN / +inf) the
+// argument val / Lmax joins `umax` -- it may overflow or be NaN.  When that test passes, x1 = val/Lmax is a positive
+// normal float (or +0): |n*log2(x1)| <= 20.4, so Lp in {0} u [7e-7, 1.4e6]; c1 + c2*Lp in [0.83, 2.7e7] and
+// 1 + c3*Lp in [1, 2.7e7] are normal, their quotient x2 lies in [0.8359, 1.0088], and m*log2(x2) in [-20.4, 1.0]:
+// the second power needs no test at all, and the result lies in [7.3e-7, 1.995].
+template <bool ANYVAL>
+LH_DEV float pq_encode_r(float val, const XformConst &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
-    const float Lp = powf_regular(div_nr(val, k.Lmax), n, *k.pw, slow);
-    return powf_regular(div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, slow);
+    const float x1 = div_nr_r(val, k.Lmax, k.rLmax);
+    float Lp;
+    if constexpr (ANYVAL) {
+        Lp = powf_regular<true, true, false>(x1, n, *k.pw, acc.flag);
+    } else {
+        acc.umax = max(acc.umax, __float_as_uint(x1) - 0x00800000u);
+        Lp = powf_regular<false, false, false>(x1, n, *k.pw, acc.flag);
+    }
+    return powf_regular<false, false, false>(div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, acc.flag);
 }
 
-LH_DEV float pq_decode_r(float val, const XformConst &k, bool &slow)
+// pq_decode_r<BOUNDED>: BOUNDED = the caller guarantees val in [0.0627, 1.79] (encode side: (219*y + 16)/255 with
+// y in [7e-7, 2]).  Then Vp = val^(1/m) lies in [0.9655, 1.0074], Vp - c1 in [0.129, 0.172] and c2 - c3*Vp in
+// [0.027, 0.81] are positive normal floats, their quotient in [0.16, 6.4], |log2|/n <= 16.8: no test anywhere.
+// Otherwise (decode side: val in [0, 1] after the reference's clamp, which also turns a NaN into 1): val is 0 (ZERO) or
+// a normal float -- it is a sum / difference of floats whose granularity is far above 2^-126 (ycbcr_inv), never a
+// denormal; Vp <= c1 gives a quotient of exactly 0 (ZERO) and Vp just above c1 one small enough for |log2|/n >= 126
+// (CHECK_E); the quotient itself is 0 or in [3e-9, 6.4], a normal float.
+template <bool BOUNDED>
+LH_DEV float pq_decode_r(float val, const XformConst &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
-    const float Vp = powf_regular(val, 1.0f / m, *k.pw, slow);
-    return k.Lmax * powf_regular(div_nr(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, slow);
+    const float Vp = powf_regular<!BOUNDED, false, false>(val, 1.0f / m, *k.pw, acc.flag);
+    return k.Lmax * powf_regular<!BOUNDED, false, !BOUNDED>(div_nr(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
 }
 
 template <int CS>
@@ -219,13 +270,13 @@ LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, f
 
 // RGB -> Y'CbCr (BT.2020, PQ): src/luma_quantizer.cpp:317-354
 template <bool REGULAR>
-LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2, bool &slow)
+LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2, SlowAcc &slow)
 {
     float R, G, B;
     if constexpr (REGULAR) {
-        R = pq_encode_r(std_max(r, 1e-10f), k, slow);
-        G = pq_encode_r(std_max(g, 1e-10f), k, slow);
-        B = pq_encode_r(std_max(b, 1e-10f), k, slow);
+        R = pq_encode_r<false>(std_max(r, 1e-10f), k, slow);
+        G = pq_encode_r<false>(std_max(g, 1e-10f), k, slow);
+        B = pq_encode_r<false>(std_max(b, 1e-10f), k, slow);
     } else {
         R = pq_encode(std_max(r, 1e-10f), k);
         G = pq_encode(std_max(g, 1e-10f), k);
@@ -233,10 +284,11 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
     }
     const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
     if constexpr (REGULAR) {
-        // 219y+16 >= 16 and 224t+128 (never -0) are finite here; |B-y|, |R-y| <= ~2.1, zero or >= ~1e-13
-        c0 = pq_decode_r(div_255_pos(219.0f * y + 16.0f), k, slow);
-        c1 = div_255_pos(224.0f * div_nr(B - y, 1.8814f) + 128.0f);
-        c2 = div_255_pos(224.0f * div_nr(R - y, 1.4746f) + 128.0f);
+        // R, G, B in [7e-7, 2] once the three input tests passed (pq_encode_r), so y is too: 219y+16 in [16, 454];
+        // 224t+128 (never -0) is finite; |B-y|, |R-y| <= ~2.1, zero or >= ~1e-13
+        c0 = pq_decode_r<true>(div_255_pos(219.0f * y + 16.0f), k, slow);
+        c1 = div_255_pos(224.0f * div_nr_r(B - y, 1.8814f, k.r18814) + 128.0f);
+        c2 = div_255_pos(224.0f * div_nr_r(R - y, 1.4746f, k.r14746) + 128.0f);
     } else {
         c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
         c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
@@ -244,15 +296,33 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
     }
 }
 
-// Straight-line evaluation first; the (rare) pixel with a NaN / inf / denormal / out-of-range power argument
-// is redone with the complete powf.  Both produce identical bits wherever the straight-line form applies.
+// N pixels at once: straight-line evaluation first; if any of them had a NaN / inf / denormal / out-of-range power
+// argument (rare), all N are redone with the complete powf.  Both produce identical bits wherever the straight-line
+// form applies.  One flag and one branch per thread and unit, not per pixel.
+template <int N>
+LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], const XformConst &k, float (&c0)[N],
+                        float (&c1)[N], float (&c2)[N])
+{
+    SlowAcc slow;
+    slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        ycbcr_fwd<true>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
+    if (__builtin_expect(slow_any(slow), 0)) {
+        for (int i = 0; i < N; i++)  // not unrolled: cold code
+            ycbcr_fwd<false>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
+    }
+}
+
 template <>
 LH_DEVS void xform_fwd<CS_YCBCR>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    bool slow = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
-    ycbcr_fwd<true>(r, g, b, k, c0, c1, c2, slow);
-    if (__builtin_expect(slow, 0))
-        ycbcr_fwd<false>(r, g, b, k, c0, c1, c2, slow);
+    const float ri[1] = {r}, gi[1] = {g}, bi[1] = {b};
+    float o0[1], o1[1], o2[1];
+    ycbcr_fwd_n<1>(ri, gi, bi, k, o0, o1, o2);
+    c0 = o0[0];
+    c1 = o1[0];
+    c2 = o2[0];
 }
 
 template <int CS>
@@ -268,16 +338,16 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 
 // Y'CbCr -> RGB: src/luma_quantizer.cpp:436-473
 template <bool REGULAR>
-LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, bool &slow)
+LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, SlowAcc &slow)
 {
     float y, blue, red, green;
     if constexpr (REGULAR) {
         // c0 is a table value in {0} u [1e-6, Lmax]; c1, c2 in [1e-10, ~260]: 255y-16 is finite and never -0,
         // the other numerators are zero or of magnitude >= ~1e-8 and <= ~1e5
-        y = div_219_fin(255.0f * pq_encode_r(c0, k, slow) - 16.0f);
-        blue = y + div_nr(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
-        red = y + div_nr(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
-        green = div_nr((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
+        y = div_219_fin(255.0f * pq_encode_r<true>(c0, k, slow) - 16.0f);
+        blue = y + div_nr_r(1.8814f * (255.0f * c1 - 128.0f), 224.0f, k.r224);
+        red = y + div_nr_r(1.4746f * (255.0f * c2 - 128.0f), 224.0f, k.r224);
+        green = div_nr_r((y - 0.2627f * red) - 0.0593f * blue, 0.6780f, k.r0678);
     } else {
         y = div_ieee(255.0f * pq_encode(c0, k) - 16.0f, 219.0f);
         blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
@@ -288,9 +358,9 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
     green = std_max(0.0f, std_min(1.0f, green));
     blue = std_max(0.0f, std_min(1.0f, blue));
     if constexpr (REGULAR) {
-        r = pq_decode_r(red, k, slow);
-        g = pq_decode_r(green, k, slow);
-        b = pq_decode_r(blue, k, slow);
+        r = pq_decode_r<false>(red, k, slow);
+        g = pq_decode_r<false>(green, k, slow);
+        b = pq_decode_r<false>(blue, k, slow);
     } else {
         r = pq_decode(red, k);
         g = pq_decode(green, k);
@@ -298,14 +368,33 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
     }
 }
 
+template <int N>
+LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const XformConst &k, float (&r)[N],
+                        float (&g)[N], float (&b)[N])
+{
+    SlowAcc slow;
+    slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        // out-of-range colour codes (c1, c2 > 1) or a non-finite table value leave the licensed ranges: slow path
+        slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f && c0[i] <= 3.0e38f);
+        ycbcr_inv<true>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+    }
+    if (__builtin_expect(slow_any(slow), 0)) {
+        for (int i = 0; i < N; i++)  // not unrolled: cold code
+            ycbcr_inv<false>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+    }
+}
+
 template <>
 LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b)
 {
-    // out-of-range colour codes (c1, c2 > 1) or a non-finite table value leave the licensed ranges: slow path
-    bool slow = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f) || !(c1 <= 1.0f && c2 <= 1.0f && c0 <= 3.0e38f);
-    ycbcr_inv<true>(c0, c1, c2, k, r, g, b, slow);
-    if (__builtin_expect(slow, 0))
-        ycbcr_inv<false>(c0, c1, c2, k, r, g, b, slow);
+    const float i0[1] = {c0}, i1[1] = {c1}, i2[1] = {c2};
+    float ro[1], go[1], bo[1];
+    ycbcr_inv_n<1>(i0, i1, i2, k, ro, go, bo);
+    r = ro[0];
+    g = go[0];
+    b = bo[0];
 }
 
 // XYZ -> RGB (before the final /sc): src/luma_quantizer.cpp:378-395 (matrix include/luma/luma_quantizer.h:84-87)

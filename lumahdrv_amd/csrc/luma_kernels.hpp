@@ -69,37 +69,27 @@ struct DecArgs {
     int do_tmo, ldr_sim;
 };
 
-// LDS layout: [lut: lut_len+pad floats, rounded to 16 B][records: nbuckets u32, rounded to 16 B][powf tables].
+// LDS layout: [powf tables (YCbCr only; FIRST, so that their addresses are immediates in the powf chains)]
+// [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B].
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
 enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8 };
 
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
 LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
 
+// offset of the search table / records behind the powf tables
 template <int WHAT>
-LH_DEV int stage_tables(unsigned char *smem, const QuantDev &q)
+constexpr int lds_table_offset() { return (WHAT & STAGE_POWF) ? (int)sizeof(PowfTables) : 0; }
+
+template <int WHAT>
+LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q)
 {
+    static_assert(sizeof(PowfTables) % 16 == 0, "the tables behind the powf tables must stay 16-byte aligned");
+    static_assert(!((WHAT & STAGE_LUT) && (WHAT & STAGE_REC)), "one search table per kernel");
     const int tid = threadIdx.x, nt = blockDim.x;
-    int off = 0;
-    if constexpr (WHAT & STAGE_LUT) {
-        // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
-        const int n4 = lds_lut_bytes(q) / 16;
-        const float4 *g = reinterpret_cast<const float4 *>(q.lut);
-        float4 *s = reinterpret_cast<float4 *>(smem);
-        for (int i = tid; i < n4; i += nt)
-            s[i] = g[i];
-        off += lds_lut_bytes(q);
-    }
-    if constexpr (WHAT & STAGE_REC) {
-        const int b4 = lds_rec_bytes(q) / 16;  // the device buffer is padded to 16 B
-        const uint4 *gb = reinterpret_cast<const uint4 *>(q.rec);
-        uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
-        for (int i = tid; i < b4; i += nt)
-            sb[i] = gb[i];
-        off += lds_rec_bytes(q);
-    }
+    constexpr int off = lds_table_offset<WHAT>();
     if constexpr (WHAT & STAGE_POWF) {
-        PowfTables *t = reinterpret_cast<PowfTables *>(smem + off);
+        PowfTables *t = reinterpret_cast<PowfTables *>(smem);
         const double lt[16][2] = LH_POWF_LOG2_TAB;
         const uint64_t et[32] = LH_POWF_EXP2_TAB;
         if (tid < 16) {
@@ -109,8 +99,22 @@ LH_DEV int stage_tables(unsigned char *smem, const QuantDev &q)
         if (tid < 32)
             t->exp2_tab[tid] = et[tid];
     }
+    if constexpr (WHAT & STAGE_LUT) {
+        // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
+        const int n4 = lds_lut_bytes(q) / 16;
+        const float4 *g = reinterpret_cast<const float4 *>(q.lut);
+        float4 *s = reinterpret_cast<float4 *>(smem + off);
+        for (int i = tid; i < n4; i += nt)
+            s[i] = g[i];
+    }
+    if constexpr (WHAT & STAGE_REC) {
+        const int b4 = lds_rec_bytes(q) / 16;  // the device buffer is padded to 16 B
+        const uint4 *gb = reinterpret_cast<const uint4 *>(q.rec);
+        uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
+        for (int i = tid; i < b4; i += nt)
+            sb[i] = gb[i];
+    }
     __syncthreads();
-    return off;  // offset of the powf tables
 }
 
 // ---- sample stores / loads ------------------------------------------------------------------------
@@ -311,11 +315,24 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
                 for (int i = 0; i < VW; i++)
                     u.in[c][r][i] *= k.sc;
     }
+    if constexpr (CS == CS_YCBCR) {
+        float r8[2 * VW], g8[2 * VW], b8[2 * VW];
 #pragma unroll
-    for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 2; r++)
 #pragma unroll
-        for (int i = 0; i < VW; i++)
-            xform_fwd<CS>(u.in[0][r][i], u.in[1][r][i], u.in[2][r][i], k, c0[r * VW + i], c1[r * VW + i], c2[r * VW + i]);
+            for (int i = 0; i < VW; i++) {
+                r8[r * VW + i] = u.in[0][r][i];
+                g8[r * VW + i] = u.in[1][r][i];
+                b8[r * VW + i] = u.in[2][r][i];
+            }
+        ycbcr_fwd_n<2 * VW>(r8, g8, b8, k, c0, c1, c2);  // one "redo with the complete powf" decision per unit
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                xform_fwd<CS>(u.in[0][r][i], u.in[1][r][i], u.in[2][r][i], k, c0[r * VW + i], c1[r * VW + i], c2[r * VW + i]);
+    }
 
     if (a.stats) {
 #pragma unroll
@@ -409,14 +426,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | (LM == 3 ? STAGE_REC : 0) | (CS == CS_YCBCR ? STAGE_POWF : 0);
-    const int pw_off = stage_tables<WHAT>(smem, a.q);
+    stage_tables<WHAT>(smem, a.q);
 
-    const float *s_lut = reinterpret_cast<const float *>(smem);        // LM == 0
-    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);  // LM == 3
-    XformConst k;
-    k.sc = a.sc;
-    k.Lmax = a.q.Lmax;
-    k.pw = reinterpret_cast<const PowfTables *>(smem + pw_off);
+    const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());        // LM == 0
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem + lds_table_offset<WHAT>());  // LM == 3
+    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTables *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -601,6 +615,17 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
 #pragma unroll
             for (int i = 0; i < VW; i++)
                 luv_apply(c0[r * VW + i], ch[SUB ? i / 2 : r * VW + i], out[0][r][i], out[1][r][i], out[2][r][i]);
+    } else if constexpr (CS == CS_YCBCR) {
+        float r8[2 * VW], g8[2 * VW], b8[2 * VW];
+        ycbcr_inv_n<2 * VW>(c0, c1, c2, k, r8, g8, b8);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < VW; i++) {
+                out[0][r][i] = r8[r * VW + i];
+                out[1][r][i] = g8[r * VW + i];
+                out[2][r][i] = b8[r * VW + i];
+            }
     } else {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -669,12 +694,10 @@ template <int CS, bool SUB, int VW, bool GL, bool DISP = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int pw_off = stage_tables<(GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0)>(smem, a.q);
-    const float *s_lut = reinterpret_cast<const float *>(smem);
-    XformConst k;
-    k.sc = a.sc;
-    k.Lmax = a.q.Lmax;
-    k.pw = reinterpret_cast<const PowfTables *>(smem + pw_off);
+    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0);
+    stage_tables<WHAT>(smem, a.q);
+    const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
+    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTables *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -721,10 +744,7 @@ __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
             s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
         __syncthreads();
     }
-    XformConst k;
-    k.sc = a.sc;
-    k.Lmax = a.Lmax;
-    k.pw = &s_pw;
+    const XformConst k = make_xform_const<CS>(a.sc, a.Lmax, &s_pw);
     const size_t total = a.n2 * a.nframes;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t f = i / a.n2, j = i - f * a.n2;
@@ -851,7 +871,7 @@ __global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_b
         float r;
         if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
             bool slow = false;
-            r = powf_regular(x, y, s_pw, slow);
+            r = powf_regular<true, true, true>(x, y, s_pw, slow);
             if (slow)
                 r = powf_glibc(x, y, s_pw);
         } else {

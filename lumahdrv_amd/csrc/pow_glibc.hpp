@@ -198,17 +198,25 @@ LH_HD float powf_glibc(float x, float y, const Tab &T)
     return (float)e;
 }
 
-// Straight-line form for the arguments the PQ transforms see almost always: x = +0, or x positive, normal and
-// finite with |y*log2(x)| < 126; y is one of the four positive PQ exponents.  For those arguments it performs
+// Straight-line form for the arguments the PQ transforms see almost always: x positive, normal and finite (or +0
+// when ZERO) with |y*log2(x)| < 126; y is one of the four positive PQ exponents.  For those arguments it performs
 // exactly the arithmetic of powf_glibc above (same operations, same order) without any of its branches; for
 // everything else it sets `slow` and returns garbage -- the caller then redoes the pixel with powf_glibc.
-// pow(+0, y > 0) = +0 is folded in as a select because black pixels are common.
-template <typename Tab>
+// What is tested is a template choice, because each test costs a half-rate compare (tools/valu_bench.hip) and the
+// call sites can often prove a test away (luma_device.hpp states the argument range at each one):
+//   ZERO    x may be +0: pow(+0, y > 0) = +0 is folded in as a select (black pixels are common on the decode side);
+//   CHECK_X x may be anything: raise `slow` unless it is a positive normal finite float (or +0 when ZERO);
+//   CHECK_E |y*log2(x)| may reach 126 (over/underflow handling of e_powf.c): raise `slow` then.
+// powf_regular<true, true, true> accepts every argument and is what tests/test_gpu_exhaustive.py sweeps.
+template <bool ZERO, bool CHECK_X, bool CHECK_E, typename Tab>
 LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
 {
     const uint32_t ix = pw_asuint(x);
-    const bool zero = (ix == 0);
-    slow = slow || (!zero && (ix - 0x00800000u >= 0x7f800000u - 0x00800000u));
+    bool zero = false;
+    if (ZERO)
+        zero = (ix == 0);
+    if (CHECK_X)
+        slow = slow || (!zero && (ix - 0x00800000u >= 0x7f800000u - 0x00800000u));
     const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
                  A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
     const uint32_t tmp = ix - 0x3f330000u;
@@ -228,22 +236,26 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
     q = __builtin_fma(p, r2, q);
     yy = __builtin_fma(yy, r4, q);
     const double ylogx = (double)y * yy;
-    slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(126.0) >> 47)));
+    if (CHECK_E)
+        slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(126.0) >> 47)));
     const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
     const double SHIFT = 0x1.8p+52 / 32;
     double kd = ylogx + SHIFT;
     const uint64_t ki = pw_asuint64(kd);
     kd -= SHIFT;
     const double rr = ylogx - kd;
-    uint64_t t = T.exp2_tab[ki % 32];
-    t += ki << (52 - 5);
+    // t = tab[ki % 32] + (ki << 47): the low 32 bits of ki << 47 are zero, so only the high word changes
+    const uint64_t t0 = T.exp2_tab[ki % 32];
+    const uint64_t t = ((uint64_t)((uint32_t)(t0 >> 32) + ((uint32_t)ki << 15)) << 32) | (uint32_t)t0;
     const double s = pw_asdouble(t);
     const double zz = __builtin_fma(C0, rr, C1);
     const double rr2 = rr * rr;
     double e = __builtin_fma(C2, rr, 1.0);
     e = __builtin_fma(zz, rr2, e);
     e = e * s;
-    return zero ? 0.0f : (float)e;
+    if (ZERO)
+        return zero ? 0.0f : (float)e;
+    return (float)e;
 }
 
 }  // namespace lh
