@@ -18,6 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libluma_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libluma_ref.so")
+REF_PLANES_TOOL = os.path.join(HERE, "_ref", "ref_planes_tool")
 
 PTF_PSI, PTF_PQ, PTF_LOG, PTF_JND_HDRVDP, PTF_LINEAR = range(5)
 CS_LUV, CS_RGB, CS_YCBCR, CS_XYZ = range(4)
@@ -27,7 +28,7 @@ def build(ref: bool = True) -> None:
     """(Re)build the oracle; the reference build is attempted only where /root/reference exists."""
     targets = ["all"]
     if ref and os.path.isdir("/root/reference/src"):
-        targets.append("ref")
+        targets += ["ref", "ref_planes"]
     subprocess.run(["make", "-s", "-C", HERE] + targets, check=True)
 
 
@@ -195,6 +196,18 @@ class Oracle:
         return out
 
 
+def _oracle_unpack(self, planes, strides, w, h, profile=2) -> np.ndarray:
+    """lo_unpack_plane x 3 = LumaDecoder::getVpxChannels on its own (no inverse colour transform)"""
+    out = np.empty((3, h, w), dtype=np.float32)
+    for p in range(3):
+        pl = np.ascontiguousarray(planes[p])
+        self.L.lo_unpack_plane(C.byref(self.q), pl.ctypes.data, int(strides[p]), p, profile, w, h, out[p].ctypes.data)
+    return out
+
+
+Oracle.unpack = _oracle_unpack
+
+
 def powf_compare(got: np.ndarray, first_bits: int, y: float, threads: int = 0):
     """(#mismatches, first mismatching bit pattern) of got[i] vs this host's libm powf(bits(first+i), y)"""
     got = np.ascontiguousarray(got, dtype=np.float32)
@@ -314,3 +327,62 @@ class RefQuantizer:
         if not ok:
             raise ValueError("unknown colour space")
         return frame
+
+
+def have_ref_planes() -> bool:
+    return os.path.exists(REF_PLANES_TOOL)
+
+
+class RefPlanes:
+    """The reference's own plane loops -- LumaEncoder::setChannels / setVpxChannel (src/luma_encoder.cpp:196-201,260-317)
+    and LumaDecoder::getVpxChannels (src/luma_decoder.cpp:205-240) -- compiled unmodified into oracle/_ref/ref_planes_tool
+    (oracle/ref_planes_harness.cpp, `make -C oracle ref_planes`) and run as a subprocess."""
+
+    def __init__(self, ptf=PTF_PQ, bitdepth=11, cs=CS_LUV, bitdepthC=8, max_lum=1e4, min_lum=0.005, lut_override=None):
+        self.cfg = (ptf, bitdepth, cs, bitdepthC, max_lum, min_lum)
+        self.lut = None if lut_override is None else np.ascontiguousarray(lut_override, dtype=np.float32)
+
+    def _run(self, mode, profile, w, h, strides, xform, sc, data: bytes):
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+            with open(inp, "wb") as f:
+                f.write(data)
+            ptf, bits, cs, bitsC, mx, mn = self.cfg
+            cmd = [REF_PLANES_TOOL, mode, str(ptf), str(bits), str(cs), str(bitsC), repr(float(mx)), repr(float(mn)),
+                   str(profile), str(w), str(h)] + [str(int(x)) for x in strides] + [str(int(xform)), repr(float(sc)), inp, outp]
+            if self.lut is not None:
+                lp = os.path.join(d, "lut.bin")
+                self.lut.tofile(lp)
+                cmd.append(lp)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("ref_planes_tool failed: %s" % r.stderr[-500:])
+            with open(outp, "rb") as f:
+                return f.read(), r.stderr
+
+    def encode(self, frame: np.ndarray, sc=1.0, profile=2, strides=None, xform=True, align=32):
+        """setChannels (after transformColorSpace when xform) -> (planes, strides, mean luminance the reference's warning
+        printed or None).  Bytes the reference does not write keep the harness's 0xA5 fill."""
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        h, w = frame.shape[1:]
+        _, hs, st, _ = plane_geometry(w, h, profile, align)
+        if strides is not None:
+            st = tuple(strides)
+        out, err = self._run("enc", profile, w, h, st, xform, sc, frame.tobytes())
+        buf = np.frombuffer(out, dtype=np.uint8)
+        planes, off = [], 0
+        for p in range(3):
+            n = hs[p] * st[p]
+            planes.append(buf[off:off + n].reshape(hs[p], st[p]).copy())
+            off += n
+        mean = None
+        for line in err.splitlines():
+            if "Mean luminance is" in line:
+                mean = float(line.split("Mean luminance is")[1].split()[0])
+        return planes, st, mean
+
+    def decode(self, planes, strides, w, h, sc=1.0, profile=2, xform=True) -> np.ndarray:
+        data = b"".join(np.ascontiguousarray(p).tobytes() for p in planes)
+        out, _ = self._run("dec", profile, w, h, strides, xform, sc, data)
+        return np.frombuffer(out, dtype=np.float32).reshape(3, h, w).copy()

@@ -6,11 +6,9 @@
  * together with this file into oracle/_ref/libluma_ref.so.  Nothing from the reference is copied
  * into the repo; this file only #includes the reference's public header and forwards calls.
  *
- * What is NOT reachable this way: LumaEncoder::setVpxChannel / LumaDecoder::getVpxChannels
- * (src/luma_encoder.cpp:260-317, src/luma_decoder.cpp:205-240) live in translation units that
- * need libvpx (a tarball whose headers include a configure-generated vpx_config.h), libebml and
- * libmatroska -- "unbuildable here" under the no-stand-ins rule.  Those two loops are pinned by the
- * Y/U/V plane digests that SURVEY.md 8(c) recorded from the full reference build instead.
+ * The plane loops LumaEncoder::setVpxChannel / LumaDecoder::getVpxChannels (src/luma_encoder.cpp:260-317,
+ * src/luma_decoder.cpp:205-240) are reached through the separate oracle/ref_planes_harness.cpp build
+ * (`make ref_planes`); this library stays the light one the bench's cpu_baseline times.
  */
 #include "luma_quantizer.h" /* /root/reference/include/luma, via -I */
 
@@ -70,8 +68,8 @@ int ref_transform_color_space(void *q, float *buf, unsigned w, unsigned h, int t
 
 /* Whole-frame encode for the bench's cpu_baseline ("kind": "reference"): the REAL
  * LumaQuantizer::transformColorSpace and LumaQuantizer::quantize (one call per sample, as the reference makes
- * them), driven by a restatement of the plane loop of LumaEncoder::setVpxChannel (src/luma_encoder.cpp:260-317),
- * which itself cannot be compiled here (it needs libvpx / libebml / libmatroska headers).  Mutates `buf` like the
+ * them), driven by a restatement of the plane loop of LumaEncoder::setVpxChannel (src/luma_encoder.cpp:260-317)
+ * (the loop itself, compiled from the reference, is oracle/_ref/ref_planes_tool; tests compare the two).  Mutates `buf` like the
  * reference does.  profile as in the reference: 0/2 = 4:2:0, 1/3 = 4:4:4; > 1 = 16-bit samples. */
 void ref_encode_frame(void *qv, float *buf, unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
                       const int stride[3], float *avg_out)

@@ -97,10 +97,57 @@ def main():
             tr["%s_inv_in_sc%g" % (name, sc)] = g.copy()
             r.transform(g, False, sc)
             tr["%s_inv_sc%g" % (name, sc)] = g
+    # ---- plane loops: LumaEncoder::setChannels / LumaDecoder::getVpxChannels, the reference's own code
+    # (oracle/_ref/ref_planes_tool), every profile, both directions, ragged sizes and a decoder-chosen stride
+    assert o.have_ref_planes()
+    pl = {}
+    for name in ("pq11_luv8", "pq10_ycbcr10", "pq12_rgb", "pq8_luv8"):
+        cfg = CONFIGS[name]
+        rp = o.RefPlanes(*cfg)
+        for (w, h) in ((34, 18), (64, 32)):
+            f = o.synth_frame(w, h, frame=5)
+            f[:, 0, :4] = [[np.nan, 0, -1, 7e4], [1, 0, 5, 7e4], [1, 0, 2, 7e4]]
+            for profile in (0, 1, 2, 3):
+                if (cfg[1] > 8) != (profile > 1):
+                    continue                    # 8-bit tables with 8-bit samples, deeper tables with 16-bit samples
+                key = "%s_%dx%d_p%d" % (name, w, h, profile)
+                planes, st, mean = rp.encode(f, 1.0 if cfg[2] != o.CS_YCBCR else 20.0, profile)
+                pl[key + "_in"] = f
+                for p in range(3):
+                    pl[key + "_plane%d" % p] = planes[p]
+                pl[key + "_stride"] = np.array(st, dtype=np.int32)
+                pl[key + "_mean"] = np.array([np.nan if mean is None else mean], dtype=np.float64)
+                # decode direction: the encoded planes with a few out-of-range / garbage codes, odd strides
+                dst = tuple(int(s) + 6 for s in st)
+                dplanes = []
+                for p in range(3):
+                    q = np.full((planes[p].shape[0], dst[p]), 0x5A, dtype=np.uint8)
+                    q[:, :st[p]] = planes[p]
+                    q[0, :8] = [0xFF, 0xFF, 0x00, 0x00, 0x34, 0x12, 0xFF, 0x7F]
+                    dplanes.append(q)
+                sc = 1.0 if cfg[2] != o.CS_YCBCR else 20.0
+                pl[key + "_dec_stride"] = np.array(dst, dtype=np.int32)
+                for p in range(3):
+                    pl[key + "_dec_plane%d" % p] = dplanes[p]
+                pl[key + "_unpacked"] = rp.decode(dplanes, dst, w, h, sc, profile, xform=False)
+                pl[key + "_decoded"] = rp.decode(dplanes, dst, w, h, sc, profile, xform=True)
+    # decode digests the survey lacks: testFrame 1280x720 through the reference's encode -> decode, profile 2 and 3
+    rp = o.RefPlanes(*CONFIGS["pq11_luv8"])
+    dig = {}
+    for profile in (2, 3):
+        planes, st, mean = rp.encode(o.test_frame(1280, 720), 1.0, profile)
+        dec = rp.decode(planes, st, 1280, 720, 1.0, profile)
+        dig["testframe_1280x720_p%d" % profile] = {
+            "Y": o.survey_digest(o.packed_rows(planes[0], 2560)), "U": o.survey_digest(o.packed_rows(planes[1], 2560 if profile == 3 else 1280)),
+            "V": o.survey_digest(o.packed_rows(planes[2], 2560 if profile == 3 else 1280)),
+            "decoded": o.survey_digest(dec), "mean_luminance_printed": mean}
+    import json
+    json.dump(dig, open(os.path.join(OUT, "ref_plane_digests.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "ref_planes.npz"), **pl)
     np.savez_compressed(os.path.join(OUT, "ref_luts.npz"), **luts)
     np.savez_compressed(os.path.join(OUT, "ref_quantize.npz"), **qv)
     np.savez_compressed(os.path.join(OUT, "ref_transform.npz"), **tr)
-    for fn in ("ref_luts.npz", "ref_quantize.npz", "ref_transform.npz"):
+    for fn in ("ref_luts.npz", "ref_quantize.npz", "ref_transform.npz", "ref_planes.npz", "ref_plane_digests.json"):
         print(fn, os.path.getsize(os.path.join(OUT, fn)), "bytes")
 
 

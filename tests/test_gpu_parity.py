@@ -505,3 +505,48 @@ def test_per_frame_statistics_exact_min_max(L, oracle_mod):
             assert s[i, 1] == t[0].min() and s[i, 2] == t[0].max(), (name, i)
             assert s[i, 0] == pytest.approx(float(t[0].astype(np.float64).sum()), rel=1e-4)
         q.ctx.set_stream(None)
+
+
+def test_planes_match_the_reference_loops_fixtures(L, golden_dir):
+    """The HIP path straight against tests/golden/ref_planes.npz -- outputs of the reference's OWN compiled
+    LumaEncoder::setChannels (after transformColorSpace) and LumaDecoder::getVpxChannels (+ inverse transform), no oracle
+    in between: 4 configurations x the profiles their bit depth allows x 2 sizes; decode side with decoder-chosen odd
+    strides and out-of-range codes.  Planes bit-exact, floats 0 ulp."""
+    gp = np.load(os.path.join(golden_dir, "ref_planes.npz"))
+    keys = sorted(k[:-3] for k in gp.files if k.endswith("_in"))
+    assert len(keys) == 16
+    for key in keys:
+        name, size, prof = key.rsplit("_", 2)
+        cfg = CONFIGS[name]
+        w, h = (int(x) for x in size.split("x"))
+        profile = int(prof[1])
+        sc = 20.0 if cfg[2] == L.CS_YCBCR else 1.0
+        q = L.LumaQuantizer()
+        q.setQuantizer(*cfg)
+        planes, st, mean = q.ctx.encode_frame(gp[key + "_in"].copy(), sc, profile)
+        assert tuple(st) == tuple(gp[key + "_stride"])
+        sub, bps = profile in (0, 2), (2 if profile > 1 else 1)
+        rb = (w * bps, ((w + 1) // 2 if sub else w) * bps, ((w + 1) // 2 if sub else w) * bps)
+        for p in range(3):
+            assert np.array_equal(planes[p][:, :rb[p]], gp[key + "_plane%d" % p][:, :rb[p]]), (key, p)
+        dst = tuple(int(x) for x in gp[key + "_dec_stride"])
+        dpl = [gp[key + "_dec_plane%d" % p] for p in range(3)]
+        assert same_bits(q.ctx.unpack_frame(dpl, dst, w, h, profile), gp[key + "_unpacked"]), key
+        assert same_bits(q.ctx.decode_frame(dpl, dst, w, h, sc, profile), gp[key + "_decoded"]), key
+
+
+def test_reference_loop_digests_on_gpu(L, oracle_mod, golden_dir):
+    """testFrame 1280x720 encode -> decode on the GPU reproduces the digests recorded from the reference's own loops
+    (tests/golden/ref_plane_digests.json): Y/U/V for profiles 2 and 3 and the decoded frame."""
+    import json
+    o = oracle_mod
+    dig = json.load(open(os.path.join(golden_dir, "ref_plane_digests.json")))
+    q = L.LumaQuantizer()
+    q.setQuantizer(*CONFIGS["pq11_luv8"])
+    for profile in (2, 3):
+        d = dig["testframe_1280x720_p%d" % profile]
+        planes, st, _ = q.ctx.encode_frame(o.test_frame(1280, 720), 1.0, profile)
+        cb = 2560 if profile == 3 else 1280
+        assert (o.survey_digest(o.packed_rows(planes[0], 2560)), o.survey_digest(o.packed_rows(planes[1], cb)),
+                o.survey_digest(o.packed_rows(planes[2], cb))) == (d["Y"], d["U"], d["V"])
+        assert o.survey_digest(q.ctx.decode_frame(planes, st, 1280, 720, 1.0, profile)) == d["decoded"]

@@ -1,6 +1,7 @@
 """The oracle against (a) the committed fixtures that tests/golden/make_golden.py generated from the real
-reference LumaQuantizer and (b), where oracle/_ref/libluma_ref.so is present, the reference itself, live.
-CPU only; bit-exact everywhere (NaN == NaN)."""
+reference -- LumaQuantizer (oracle/_ref/libluma_ref.so) and the plane loops LumaEncoder::setChannels /
+LumaDecoder::getVpxChannels (oracle/_ref/ref_planes_tool), both compiled unmodified -- and (b), where those builds
+are present, the reference itself, live.  CPU only; bit-exact everywhere (NaN == NaN)."""
 import os
 
 import numpy as np
@@ -134,3 +135,115 @@ def test_live_reference_whole_frame_encode(oracle_mod):
     r = o.RefQuantizer(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
     planes, _, _ = r.encode(o.test_frame(1280, 720), 1.0, 2)
     assert o.survey_digest(o.packed_rows(planes[0], 2560)) == "e0ff09731298e8f6"
+
+
+# ---- the plane loops: LumaEncoder::setChannels / setVpxChannel (src/luma_encoder.cpp:196-201,260-317) and
+# ---- LumaDecoder::getVpxChannels (src/luma_decoder.cpp:205-240), pinned by the reference's own compiled code
+
+def _plane_keys(gp):
+    return sorted(k[:-3] for k in gp.files if k.endswith("_in"))
+
+
+def _row_bytes(w, h, profile):
+    sub = profile in (0, 2)
+    bps = 2 if profile > 1 else 1
+    cw = (w + 1) // 2 if sub else w
+    return (w * bps, cw * bps, cw * bps)
+
+
+def test_plane_loops_match_reference_fixtures(oracle_mod, golden_dir):
+    """lo_pack_plane / lo_unpack_plane (and the whole-frame drivers built on them) against what the reference's own
+    setChannels / getVpxChannels produced: four configurations x the profiles their bit depth allows x two frame sizes,
+    NaN / zero / negative / huge pixels, decoder-chosen odd strides, out-of-range codes."""
+    o = oracle_mod
+    gp = np.load(os.path.join(golden_dir, "ref_planes.npz"))
+    keys = _plane_keys(gp)
+    assert len(keys) == 16 and {int(k[-1]) for k in keys} == {0, 1, 2, 3}
+    for key in keys:
+        name, size, prof = key.rsplit("_", 2)
+        cfg = CONFIGS[name]
+        w, h = (int(x) for x in size.split("x"))
+        profile = int(prof[1])
+        sc = 20.0 if cfg[2] == o.CS_YCBCR else 1.0
+        qq = o.Oracle(*cfg, table=table_for(o, cfg))
+        planes, st, mean = qq.encode(gp[key + "_in"].copy(), sc, profile)
+        assert tuple(st) == tuple(gp[key + "_stride"])
+        rb = _row_bytes(w, h, profile)
+        for p in range(3):
+            ref = gp[key + "_plane%d" % p]
+            assert np.array_equal(planes[p][:, :rb[p]], ref[:, :rb[p]]), (key, p)
+            assert np.all(ref[:, rb[p]:] == 0xA5)            # the reference writes the samples and nothing else
+        printed = float(gp[key + "_mean"][0])
+        if not np.isnan(printed):                             # the warning fired: avg <= 1 (src/luma_encoder.cpp:313-316)
+            assert mean <= 1.0 and abs(mean - printed) <= 5e-7 * max(1.0, abs(printed))   # %f prints 6 decimals
+        dst = tuple(int(x) for x in gp[key + "_dec_stride"])
+        dpl = [gp[key + "_dec_plane%d" % p] for p in range(3)]
+        assert same(qq.unpack(dpl, dst, w, h, profile), gp[key + "_unpacked"]), key
+        assert same(qq.decode(dpl, dst, w, h, sc, profile), gp[key + "_decoded"]), key
+
+
+def test_plane_digests_from_the_reference_loops(oracle_mod, golden_dir):
+    """testFrame 1280x720 through encode -> decode: digests recorded from the reference's own loops, incl. the decode
+    direction and the 4:4:4 profile that SURVEY.md 8(c) lacks; the profile-2 Y/U/V digests equal the survey's."""
+    import json
+    o = oracle_mod
+    dig = json.load(open(os.path.join(golden_dir, "ref_plane_digests.json")))
+    assert (dig["testframe_1280x720_p2"]["Y"], dig["testframe_1280x720_p2"]["U"], dig["testframe_1280x720_p2"]["V"]) == \
+        ("e0ff09731298e8f6", "4c410839cf4228cc", "28868357f4a5e5e5")
+    qq = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    for profile in (2, 3):
+        d = dig["testframe_1280x720_p%d" % profile]
+        planes, st, _ = qq.encode(o.test_frame(1280, 720), 1.0, profile)
+        cb = 2560 if profile == 3 else 1280
+        assert o.survey_digest(o.packed_rows(planes[0], 2560)) == d["Y"]
+        assert o.survey_digest(o.packed_rows(planes[1], cb)) == d["U"]
+        assert o.survey_digest(o.packed_rows(planes[2], cb)) == d["V"]
+        assert o.survey_digest(qq.decode(planes, st, 1280, 720, 1.0, profile)) == d["decoded"]
+
+
+def test_live_reference_plane_loops(oracle_mod):
+    """oracle vs the reference's compiled setChannels / getVpxChannels on fresh frames: every configuration, every
+    profile, ragged sizes, odd strides, an attachment-434 style table override.  Also the mean luminance the reference
+    prints in its warning (sequential fp32 sum) against the oracle's."""
+    o = oracle_mod
+    if not o.have_ref_planes():
+        pytest.skip("oracle/_ref/ref_planes_tool not built (needs /root/reference)")
+    rng = np.random.default_rng(77)
+    for name, cfg in CONFIGS.items():
+        qq = o.Oracle(*cfg, table=table_for(o, cfg))
+        rp = o.RefPlanes(*cfg)
+        sc = 20.0 if cfg[2] == o.CS_YCBCR else 1.0
+        for (w, h) in ((6, 2), (50, 22)):
+            f = np.exp(rng.uniform(np.log(1e-4), np.log(3e4), size=(3, h, w))).astype(np.float32)
+            f[:, 0, :3] = [[np.nan, 0, -2], [1, 0, 5], [1, 0, 2]]
+            for profile in (0, 1, 2, 3):
+                bps = 2 if profile > 1 else 1
+                _, hs, st0, _ = o.plane_geometry(w, h, profile)
+                st = tuple(s + 2 * p + 1 for p, s in enumerate(st0))             # odd, different per plane
+                a, _, _ = qq.encode(f.copy(), sc, profile)
+                b, _, _ = rp.encode(f.copy(), sc, profile, strides=st)
+                rb = _row_bytes(w, h, profile)
+                for p in range(3):
+                    assert np.array_equal(a[p][:, :rb[p]], b[p][:, :rb[p]]), (name, w, h, profile, p)
+                    assert np.all(b[p][:, rb[p]:] == 0xA5)
+                garbage = [np.where(rng.random(x.shape) < 0.02, rng.integers(0, 256, x.shape), x).astype(np.uint8) for x in b]
+                assert same(qq.unpack(garbage, st, w, h, profile), rp.decode(garbage, st, w, h, sc, profile, xform=False)), (name, profile)
+                assert same(qq.decode(garbage, st, w, h, sc, profile), rp.decode(garbage, st, w, h, sc, profile)), (name, profile)
+    # dark frame: the reference prints its warning; its number is the sequential fp32 sum / (w*h)
+    qq = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    rp = o.RefPlanes(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    dark = (o.synth_frame(320, 180, frame=1) * np.float32(1e-5)).astype(np.float32)
+    _, _, mo = qq.encode(dark.copy(), 1.0, 2)
+    _, _, mr = rp.encode(dark.copy(), 1.0, 2)
+    assert mr is not None and abs(mo - mr) <= 5e-7
+    # table override (LumaDecoder::initialize, src/luma_decoder.cpp:121-122)
+    lut = qq.mapping.copy()
+    lut[100:110] *= np.float32(1.01)
+    q2 = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    q2.overwrite_mapping(lut)
+    rp2 = o.RefPlanes(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005, lut_override=lut[:-1])   # getSize() = maxVal floats
+    lut_eff = lut.copy()
+    lut_eff[-1] = qq.mapping[-1]
+    q2.overwrite_mapping(lut_eff)
+    planes, st, _ = q2.encode(o.synth_frame(64, 32, frame=9), 1.0, 2)
+    assert same(q2.decode(planes, st, 64, 32, 1.0, 2), rp2.decode(planes, st, 64, 32, 1.0, 2))
