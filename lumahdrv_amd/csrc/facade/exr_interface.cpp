@@ -30,7 +30,7 @@ struct Reader {
     explicit Reader(const Bytes &bytes) : b(bytes), p(0) {}
     void need(size_t n) const
     {
-        if (p + n > b.size())
+        if (n > b.size() || p > b.size() - n)  // no p + n: p may come from an untrusted 64-bit chunk offset
             throw LumaException("EXR: unexpected end of file");
     }
     int32_t i32()
@@ -244,12 +244,16 @@ static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
                 chans.push_back(c);
             }
         } else if (name == "compression") {
+            if (size < 1)
+                throw LumaException("EXR: malformed compression attribute");
             compression = data[rd.p];
         } else if (name == "dataWindow") {
             for (int i = 0; i < 4; i++)
                 dw[i] = rd.i32();
             haveDW = true;
         } else if (name == "lineOrder") {
+            if (size < 1)
+                throw LumaException("EXR: malformed lineOrder attribute");
             lineOrder = data[rd.p];
         }
         rd.p = end;
@@ -314,6 +318,8 @@ static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
     Bytes raw, tmp;
     for (long blk = 0; blk < nblocks; blk++) {
         Reader c(data);
+        if (offsets[(size_t)blk] >= (uint64_t)data.size())
+            throw LumaException("EXR: chunk offset outside the file");
         c.p = (size_t)offsets[(size_t)blk];
         const int32_t y0 = c.i32();
         const int32_t dsz = c.i32();

@@ -117,7 +117,15 @@ LumaFrame *LumaDecoder::decode()
         m_frame.width = m_vpxFrame->d_w;
         m_frame.height = m_vpxFrame->d_h;
         m_frame.channels = 3;
-        m_frame.init();
+        bool ok = false;
+        try {
+            ok = m_frame.init();
+        } catch (const std::exception &) {   // std::bad_alloc: callers catch LumaException, as the reference's apps do
+        }
+        if (!ok) {
+            m_frame.width = m_frame.height = 0;
+            throw LumaException("Cannot allocate memory for the decoded frame");
+        }
     }
     const unsigned char *pl[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
     const int rc = lumahip_decode_frame_host(m_quant.context(), pl, m_vpxFrame->stride, m_vpxFrame->d_w, m_vpxFrame->d_h,

@@ -2,6 +2,7 @@
 #include "../../../include/luma/luma_planes.h"
 
 #include <cstring>
+#include <exception>
 
 #include "../../../include/luma/luma_exception.h"
 
@@ -140,7 +141,26 @@ void LumaRawStreamReader::open(const char *file)
         m_att.push_back(a);
     }
     m_dataStart = ftell(m_f);
-    m_buf.allocate(m_w, m_h, m_profile);
+    // A corrupt header must not make us allocate gigabytes (65536 x 65536 would be ~25 GB of planes plus a 51 GB float
+    // frame in the decoder): the file has to hold at least one whole frame of the announced geometry.
+    {
+        const bool sub = (m_profile == 0 || m_profile == 2);
+        const size_t bps = m_profile > 1 ? 2 : 1;
+        const size_t cw = sub ? (m_w + 1) / 2 : m_w, chh = sub ? (m_h + 1) / 2 : m_h;
+        const size_t need = ((size_t)m_w * m_h + 2 * cw * chh) * bps;
+        long end = -1;
+        if (fseek(m_f, 0, SEEK_END) == 0)
+            end = ftell(m_f);
+        if (end < 0 || fseek(m_f, m_dataStart, SEEK_SET) != 0)
+            throw LumaException(std::string("cannot determine the size of '") + file + "'");
+        if ((size_t)(end - m_dataStart) < need)
+            throw LumaException(std::string("'") + file + "' is too short for one frame of the announced size");
+    }
+    try {
+        m_buf.allocate(m_w, m_h, m_profile);
+    } catch (const std::exception &e) {
+        throw LumaException(std::string("cannot allocate the plane buffer: ") + e.what());
+    }
     m_frameBytes = 0;
     const LumaPlanes &im = m_buf.image();
     for (int p = 0; p < 3; p++)

@@ -57,9 +57,9 @@ struct lumahip_ctx {
     float *h_stats = nullptr;  // pinned, 3 floats per frame
     size_t h_stats_cap = 0;
 
-    int cs_override = -1;  // CS_PACK / CS_RGB while a pack-only / unpack-only call is in flight
     int block_threads = 256;
     bool block_forced = false;
+    bool allow_alias = false;  // LUMAHIP_ALLOW_ALIASED_FRAMES=1: measurement tools alias all frames of a batch onto one
     int blocks_per_cu = 0;  // 0 = occupancy query
 };
 
@@ -132,6 +132,8 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
     }
     if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
         c->blocks_per_cu = atoi(e);
+    if (const char *e = getenv("LUMAHIP_ALLOW_ALIASED_FRAMES"))
+        c->allow_alias = atoi(e) != 0;
     *out = c;
     return LUMAHIP_OK;
 }
@@ -278,7 +280,7 @@ extern "C" int lumahip_thresh_index_host(const float *lut, size_t n, int info[5]
 }
 
 // dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)
-static size_t lds_bytes(const lumahip_ctx *c, bool encode_side)
+static size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
 {
     const QuantDev &q = c->q;
     size_t b = 0;
@@ -291,7 +293,6 @@ static size_t lds_bytes(const lumahip_ctx *c, bool encode_side)
     } else if (c->lut_in_lds) {
         b += lut_b;
     }
-    const int cs_eff = c->cs_override >= 0 ? c->cs_override : q.cs;
     if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTables);
     return b;
@@ -321,7 +322,7 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
     info[1] = c->tix.ok ? c->tix.mant_bits : 0;
     info[2] = c->q.nbuckets;
     info[3] = c->tix.ok ? c->tix.shift : 0;
-    info[4] = (int)lds_bytes(c, true);
+    info[4] = (int)lds_bytes(c, true, c->q.cs);
     return LUMAHIP_OK;
 }
 
@@ -379,7 +380,7 @@ static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp)
     return nullptr;
 }
 
-static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile)
+static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff)
 {
     if (!c->have_quant)
         return fail(c, LUMAHIP_ERR_STATE, "quantizer not set (call lumahip_set_quantizer first)");
@@ -387,8 +388,8 @@ static int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile)
         return fail(c, LUMAHIP_ERR_ARG, "Invalid frame size %ux%u (must be even, non-zero)", w, h);
     if (profile < 0 || profile > 3)
         return fail(c, LUMAHIP_ERR_ARG, "profile must be 0..3 (got %d)", profile);
-    if (c->cs_override < 0 && (c->q.cs < 0 || c->q.cs > 3))
-        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", c->q.cs);
+    if (cs_eff < 0 || cs_eff > CS_PACK)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", cs_eff);
     return LUMAHIP_OK;
 }
 
@@ -424,6 +425,21 @@ static int grid_for(const lumahip_ctx *c, int threads, int total_tiles)
 
 static bool is_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
+// a pair of timing events that cannot leak on an early return
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create()
+    {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
 __global__ void k_init_stats(float *s, int nframes)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,15 +450,43 @@ __global__ void k_init_stats(float *s, int nframes)
     }
 }
 
-extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
-                                            unsigned w, unsigned h, float sc, int profile,
-                                            unsigned char *const planes[3], const int stride[3],
-                                            const size_t pfs[3], float *stats)
+// rows and bytes per row of plane p as vpx_img_alloc lays it out (src/luma_encoder.cpp:121-128)
+static void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes)
+{
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    rows = (p && sub) ? (int)(h + 1) / 2 : (int)h;
+    row_bytes = ((p && sub) ? (int)(w + 1) / 2 : (int)w) * bps;
+}
+
+// the device entry points take caller-chosen strides: reject layouts in which rows or frames would overlap or the
+// kernels would write outside a plane (negative / too small strides, frame strides smaller than a frame)
+static int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, size_t frame_stride,
+                        const int stride[3], const size_t pfs[3])
+{
+    for (int p = 0; p < 3; p++) {
+        int rows, row_bytes;
+        plane_dims(w, h, profile, p, rows, row_bytes);
+        if (stride[p] < row_bytes)
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: stride %d < row bytes %d", p, stride[p], row_bytes);
+        if (nframes > 1 && !c->allow_alias && pfs[p] < (size_t)rows * (size_t)stride[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: frame stride %zu < plane size %zu", p, pfs[p], (size_t)rows * stride[p]);
+    }
+    if (nframes > 1 && !c->allow_alias && frame_stride < (size_t)3 * w * h)
+        return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < 3*w*h = %zu floats", frame_stride, (size_t)3 * w * h);
+    return LUMAHIP_OK;
+}
+
+static int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w,
+                                     unsigned h, float sc, int profile, unsigned char *const planes[3], const int stride[3],
+                                     const size_t pfs[3], float *stats, int cs_eff)
 {
     if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
+        return rc;
+    if ((rc = check_layout(c, w, h, profile, nframes, frame_stride, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const bool sub = (profile == 0 || profile == 2);
@@ -454,7 +498,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
         return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
     EncArgs a{};
     a.q = c->q;
-    const size_t lds = lds_bytes(c, true);
+    const size_t lds = lds_bytes(c, true, cs_eff);
     const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
@@ -474,7 +518,6 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
         if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
             a.aligned = 0;
     }
-    const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
     enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
     if (lds > 64 * 1024)
@@ -487,6 +530,16 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
     return LUMAHIP_OK;
 }
 
+extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
+                                            unsigned w, unsigned h, float sc, int profile,
+                                            unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], float *stats)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return encode_frames_device_impl(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+}
+
 struct DisplayParams {
     unsigned char *rgba = nullptr;
     int stride = 0;
@@ -497,12 +550,14 @@ struct DisplayParams {
 
 static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                        unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
-                       const DisplayParams &dp)
+                       const DisplayParams &dp, int cs_eff)
 {
     if (!c || (!rgb && !dp.rgba) || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
+        return rc;
+    if ((rc = check_layout(c, w, h, profile, nframes, rgb ? frame_stride : (size_t)3 * w * h, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const bool sub = (profile == 0 || profile == 2);
@@ -515,7 +570,7 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
         return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
     DecArgs a{};
     a.q = c->q;
-    const size_t lds = lds_bytes(c, false);
+    const size_t lds = lds_bytes(c, false, cs_eff);
     const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
@@ -541,7 +596,6 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
         if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
             a.aligned = 0;
     }
-    const int cs_eff = c->cs_override >= 0 ? c->cs_override : c->q.cs;
     a.q.cs = cs_eff;
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
     if (lds > 64 * 1024)
@@ -558,7 +612,9 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
 {
     if (!rgb)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb, frame_stride, DisplayParams());
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb, frame_stride, DisplayParams(), c->q.cs);
 }
 
 extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsigned char *const planes[3],
@@ -568,6 +624,8 @@ extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsign
                                                     size_t rgba_frame_stride, float exposure, float gamma, int do_tmo,
                                                     int ldr_sim)
 {
+    if (!c)
+        return LUMAHIP_ERR_ARG;
     if (!rgba || !(gamma > 0.0f))
         return fail(c, LUMAHIP_ERR_ARG, "display output needs a buffer and gamma > 0");
     DisplayParams dp;
@@ -578,7 +636,7 @@ extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsign
     dp.gamma = gamma;
     dp.do_tmo = do_tmo;
     dp.ldr_sim = ldr_sim;
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_or_null, frame_stride, dp);
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_or_null, frame_stride, dp, c->q.cs);
 }
 
 typedef void (*xf_kernel_t)(const XfArgs);
@@ -671,18 +729,15 @@ extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *
         a.dst_frame_stride[p] = pfs[p];
     }
     const int grid = grid_for(c, threads, a.g.totalTiles);
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    HIPCHK(c, hipEventRecord(e0, c->stream));
+    EventPair ev;
+    HIPCHK(c, ev.create());
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
     for (int i = 0; i < iters; i++)
         hipLaunchKernelGGL(k_encode_traffic_probe, dim3(grid), dim3(threads), 0, c->stream, a);
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
     float ms = 0.0f;
-    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     HIPCHK(c, hipGetLastError());
     *avg_ms = ms / iters;
     return LUMAHIP_OK;
@@ -696,11 +751,10 @@ extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const f
     if (!c || iters <= 0 || !avg_ms)
         return fail(c, LUMAHIP_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(c, ev.create());
     int rc = LUMAHIP_OK;
-    HIPCHK(c, hipEventRecord(e0, c->stream));
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
     for (int i = 0; i < iters && rc == LUMAHIP_OK; i++) {
         if (dir == 0)
             rc = lumahip_encode_frames_device(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, nullptr);
@@ -708,12 +762,10 @@ extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const f
             rc = lumahip_decode_frames_device(c, (const unsigned char *const *)planes, stride, pfs, nframes, w, h, profile,
                                               sc, const_cast<float *>(rgb), frame_stride);
     }
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
     float ms = 0.0f;
-    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *avg_ms = ms / iters;
     return rc;
 }
@@ -756,13 +808,13 @@ static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, co
     L.total = off;
 }
 
-extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
-                                         unsigned char *const planes[3], const int stride[3], float *mean_lum,
-                                         float *transformed_out)
+static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                  unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                                  float *transformed_out, int cs_eff)
 {
     if (!c || !rgb || !planes || !stride)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -783,7 +835,7 @@ extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsig
     HIPCHK(c, hipMemcpyAsync(c->d_frame, rgb, nfl * sizeof(float), hipMemcpyHostToDevice, c->stream));
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
     const size_t pfs[3] = {0, 0, 0};
-    rc = lumahip_encode_frames_device(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats);
+    rc = encode_frames_device_impl(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
     if (rc)
         return rc;
     for (int p = 0; p < 3; p++)
@@ -803,12 +855,21 @@ extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsig
     return LUMAHIP_OK;
 }
 
-extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
-                                         unsigned w, unsigned h, int profile, float sc, float *rgb_out)
+extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                         unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                                         float *transformed_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return encode_frame_host_impl(c, rgb, w, h, sc, profile, planes, stride, mean_lum, transformed_out, c->q.cs);
+}
+
+static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], unsigned w,
+                                  unsigned h, int profile, float sc, float *rgb_out, int cs_eff)
 {
     if (!c || !rgb_out || !planes || !stride)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -827,12 +888,20 @@ extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *co
         HIPCHK(c, hipMemcpy2DAsync(dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p],
                                    hipMemcpyHostToDevice, c->stream));
     const size_t pfs[3] = {0, 0, 0};
-    rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl);
+    rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl, DisplayParams(), cs_eff);
     if (rc)
         return rc;
     HIPCHK(c, hipMemcpyAsync(rgb_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                         unsigned w, unsigned h, int profile, float sc, float *rgb_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return decode_frame_host_impl(c, planes, stride, w, h, profile, sc, rgb_out, c->q.cs);
 }
 
 // ---- batched host entry points: a 3-slot software pipeline over three streams.  Frame i's H2D copy runs while
@@ -880,7 +949,7 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
 {
     if (!c || !rgb || !planes || !stride || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, c->q.cs);
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -942,7 +1011,7 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
 {
     if (!c || !rgb_out || !planes || !stride || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    int rc = check_geom(c, w, h, profile);
+    int rc = check_geom(c, w, h, profile, c->q.cs);
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1085,10 +1154,7 @@ static int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t 
     if (grid > (long)c->num_cu * 8)
         grid = (long)c->num_cu * 8;
     if (quant) {
-        const int cs_saved = c->cs_override;
-        c->cs_override = CS_PACK;  // no powf tables for the array kernels
-        const size_t lds = lds_bytes(c, true);
-        c->cs_override = cs_saved;
+        const size_t lds = lds_bytes(c, true, CS_PACK);  // no powf tables for the array kernels
         void (*kern)(const QArrArgs) = k_quantize_array<2>;
         switch (c->q.mode) {
         case LUT_LITERAL_LDS: kern = k_quantize_array<0>; break;
@@ -1129,10 +1195,7 @@ extern "C" int lumahip_pack_frame_host(lumahip_ctx *c, const float *transformed,
         return LUMAHIP_ERR_ARG;
     if (!c->have_quant)
         return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
-    c->cs_override = pack_cs(c);
-    const int rc = lumahip_encode_frame_host(c, transformed, w, h, 1.0f, profile, planes, stride, mean_lum, nullptr);
-    c->cs_override = -1;
-    return rc;
+    return encode_frame_host_impl(c, transformed, w, h, 1.0f, profile, planes, stride, mean_lum, nullptr, pack_cs(c));
 }
 
 extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
@@ -1142,10 +1205,7 @@ extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *co
         return LUMAHIP_ERR_ARG;
     if (!c->have_quant)
         return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
-    c->cs_override = pack_cs(c);
-    const int rc = lumahip_decode_frame_host(c, planes, stride, w, h, profile, 1.0f, dequantized_out);
-    c->cs_override = -1;
-    return rc;
+    return decode_frame_host_impl(c, planes, stride, w, h, profile, 1.0f, dequantized_out, pack_cs(c));
 }
 
 // ---------------------------------------------------------------------------------------- memory helpers
@@ -1170,10 +1230,7 @@ extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, 
     if (!c->have_quant)
         return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
     HIPCHK(c, hipSetDevice(c->device));
-    const int cs_saved = c->cs_override;
-    c->cs_override = CS_PACK;
-    const size_t lds = lds_bytes(c, true);
-    c->cs_override = cs_saved;
+    const size_t lds = lds_bytes(c, true, CS_PACK);
     void (*kern)(const QuantDev, uint16_t *, uint32_t, size_t) = nullptr;
     switch (c->q.mode) {
     case LUT_LITERAL_LDS: kern = nonneg ? k_quantize_probe<0, true> : k_quantize_probe<0, false>; break;

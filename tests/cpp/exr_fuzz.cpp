@@ -1,6 +1,6 @@
 // tests/cpp/exr_fuzz.cpp -- mutation fuzzing of ExrInterface::readFrame under ASan + UBSan.
-// Writes a valid file with ExrInterface::writeFrame, then corrupts it (byte flips, truncation, size-field
-// stomping) N times; every attempt must either decode or throw LumaException -- never crash, hang or overrun.
+// Writes a valid file with ExrInterface::writeFrame, then corrupts it (byte flips, truncation, 32-bit size-field
+// stomping, 64-bit chunk-offset stomping incl. values that wrap p + n) N times; every attempt must either decode or throw LumaException -- never crash, hang or overrun.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +38,7 @@ int main(int argc, char **argv)
         }
         for (int it = 0; it < iters; it++) {
             std::vector<unsigned char> m = data;
-            const unsigned kind = rnd() % 4;
+            const unsigned kind = rnd() % 5;
             if (kind == 0) {
                 m.resize(rnd() % m.size());  // truncation
             } else if (kind == 1) {
@@ -48,6 +48,13 @@ int main(int argc, char **argv)
                 const size_t p = rnd() % (m.size() - 4);  // stomp a 32-bit field with an extreme value
                 const unsigned vals[4] = {0xffffffffu, 0x7fffffffu, 0x80000000u, 0u};
                 memcpy(&m[p], &vals[rnd() % 4], 4);
+            } else if (kind == 3) {
+                // stomp an aligned-or-not 64-bit field (the chunk offset table lives right after the header) with values
+                // that wrap `offset + size` arithmetic or point just past / far past the end of the file
+                const size_t p = rnd() % (m.size() - 8);
+                const unsigned long long vals[6] = {0xfffffffffffffffeull, 0xfffffffffffffff8ull, 0x8000000000000000ull,
+                                                    (unsigned long long)m.size(), (unsigned long long)m.size() - 1, 0x100000000ull};
+                memcpy(&m[p], &vals[rnd() % 6], 8);
             } else {
                 const size_t p = rnd() % m.size(), n = rnd() % 64;
                 for (size_t k = p; k < m.size() && k < p + n; k++)

@@ -209,3 +209,41 @@ def test_reader_survives_corrupted_files_under_sanitizers(tmp_path):
     assert r.stdout.startswith("ok ")
     d, rj = [int(x.split("=")[1]) for x in r.stdout.split()[1:3]]
     assert d + rj == 1600 and rj > 200
+
+
+def test_wrapping_chunk_offsets_and_empty_attributes_are_rejected(tmp_path):
+    """Directed cases from the round-1 review, reader + CLI built with ASan + UBSan (no GPU library needed: exr_tool links
+    the reader source directly): a 64-bit chunk offset that wraps `p + n` (0xFFFFFFFFFFFFFFFE), offsets at / past the end
+    of the file, and a zero-size `compression` / `lineOrder` attribute as the last bytes of a truncated file."""
+    exe = str(tmp_path / "exr_tool_asan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "exr_tool.cpp"),
+                    os.path.join(ROOT, "lumahdrv_amd", "csrc", "facade", "exr_interface.cpp"), "-o", exe, "-lz"], check=True)
+    rng = np.random.default_rng(4)
+    chans = {n: rng.uniform(0, 100, (18, 20)).astype(np.float16) for n in "RGB"}
+    for comp in (0, 2, 3):
+        good = str(tmp_path / ("good%d.exr" % comp))
+        write_exr_py(good, chans, comp)
+        d = bytearray(open(good, "rb").read())
+        p = 8
+        while d[p] != 0:                                  # walk the attributes to the offset table
+            p = d.index(b"\0", p) + 1
+            p = d.index(b"\0", p) + 1
+            p += 4 + struct.unpack_from("<i", d, p)[0]
+        table = p + 1
+        r = subprocess.run([exe, "read", good, str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for v in (0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFF8, 0x8000000000000000, len(d), len(d) - 1, len(d) - 7, 1 << 32):
+            m = bytearray(d)
+            struct.pack_into("<Q", m, table, v)
+            bad = str(tmp_path / "bad.exr")
+            open(bad, "wb").write(m)
+            r = subprocess.run([exe, "read", bad, str(tmp_path / "o.bin")], capture_output=True, text=True)
+            assert r.returncode == 1 and "LumaException" in r.stderr, (comp, hex(v), r.returncode, r.stderr[-600:])
+    # zero-size compression / lineOrder attribute at the very end of the data
+    for name, typ in (("compression", "compression"), ("lineOrder", "lineOrder")):
+        hdr = struct.pack("<ii", 20000630, 2) + attr(name, typ, b"")
+        bad = str(tmp_path / "short.exr")
+        open(bad, "wb").write(hdr)
+        r = subprocess.run([exe, "read", bad, str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 1 and "LumaException" in r.stderr, (name, r.returncode, r.stderr[-600:])

@@ -220,6 +220,25 @@ def test_unaligned_strides_and_bad_arguments(L, oracle_mod):
     bad = L.LumaQuantizer()
     bad.setQuantizer(L.PTF_PQ, 11, 9, 8, 1e4, 0.005)   # unknown colour space: transformColorSpace returns false
     assert bad.transformColorSpace(np.ones((3, 2, 2), dtype=np.float32), True, 1.0) is False
+    # device entry points: layouts in which rows / frames would overlap or fall outside a plane are refused
+    import torch
+    dev = torch.device("cuda:0")
+    w, h, n3 = 64, 32, 3 * 64 * 32
+    src = torch.zeros(2 * n3, dtype=torch.float32, device=dev)
+    out = torch.zeros(2 * n3, dtype=torch.float32, device=dev)
+    pl = [torch.zeros(2 * 32 * 128, dtype=torch.uint8, device=dev) for _ in range(3)]
+    ptr = [t.data_ptr() for t in pl]
+    ok_st, ok_pfs = (128, 64, 64), (32 * 128, 16 * 64, 16 * 64)
+    q.ctx.encode_frames_device(src.data_ptr(), n3, 2, w, h, 1.0, 2, ptr, ok_st, ok_pfs)           # the valid layout
+    q.ctx.decode_frames_device(ptr, ok_st, ok_pfs, 2, w, h, 2, 1.0, out.data_ptr(), n3)
+    for st_, pfs_, fs_ in (((126, 64, 64), ok_pfs, n3), ((128, 62, 64), ok_pfs, n3), ((-128, 64, 64), ok_pfs, n3),
+                           (ok_st, (0, 0, 0), n3), (ok_st, (32 * 128 - 2, 16 * 64, 16 * 64), n3), (ok_st, ok_pfs, n3 - 2),
+                           (ok_st, ok_pfs, 0)):
+        with pytest.raises(L.LumaHipError):
+            q.ctx.encode_frames_device(src.data_ptr(), fs_, 2, w, h, 1.0, 2, ptr, st_, pfs_)
+        with pytest.raises(L.LumaHipError):
+            q.ctx.decode_frames_device(ptr, st_, pfs_, 2, w, h, 2, 1.0, out.data_ptr(), fs_)
+    torch.cuda.synchronize()
 
 
 def test_full_size_4k_frame_and_properties(L, oracle_mod):

@@ -125,3 +125,16 @@ def test_threshold_records_equal_the_reference_search(L, oracle_mod, golden_dir)
     assert not capi.thresh_index(nanlut)["ok"]
     ix13 = capi.thresh_index(L.build_lut(L.PTF_PQ, 13))
     assert ix13["ok"] and ix13["nbuckets"] * 4 > (72 << 10)                         # global-memory records
+
+
+def test_raw_stream_reader_rejects_crafted_headers(L, tmp_path):
+    """LumaRawStreamReader::open (facade, upstream of LumaDecoder::decode) bounds the announced geometry by the file
+    size and reports every malformed header as LumaException -- round-1 review: a 65536x65536 header made it allocate
+    ~25 GB and die with std::bad_alloc.  CPU only (no context is created)."""
+    lib = os.path.join(ROOT, "lumahdrv_amd", "lib")
+    exe = str(tmp_path / "raw_stream_reject")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "raw_stream_reject.cpp"), "-o", exe, "-L" + lib, "-lluma_hip", "-llumahip",
+                    "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

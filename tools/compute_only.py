@@ -15,6 +15,7 @@ import lumahdrv_amd as L  # noqa: E402
 
 
 def main():
+    os.environ["LUMAHIP_ALLOW_ALIASED_FRAMES"] = "1"   # frame stride 0 is refused otherwise (rows of different frames overlap)
     dev = torch.device("cuda:0")
     ctx = L.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
