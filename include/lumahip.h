@@ -170,6 +170,17 @@ int lumahip_decode_display_frames_device(lumahip_ctx *ctx, const unsigned char *
 int lumahip_transform_color_space_device(lumahip_ctx *ctx, float *frames_dev, size_t frame_stride, unsigned nframes,
                                          unsigned w, unsigned h, int toCs, float sc);
 
+/* The reference's mean luminance of ONE device-resident frame, bit for bit: transformed channel 0 accumulated into a single
+ * fp32 variable in raster order, divided by (float)(w*h) (LumaEncoder::setVpxChannel, src/luma_encoder.cpp:276,294,314; the
+ * reference warns when it is <= 1).  Tens of ms at 4K (the sum is sequential by definition); synchronous.  The `mean_lum`
+ * of the host entry points and the per-frame `sum` statistic of lumahip_encode_frames_device come from the encode kernel
+ * instead: an accurate sum, whereas the reference's drops / rounds small addends once its running sum is large (-0.2 % at
+ * 1080p, several % at 4K on wide-range content).  The host entry points call this function themselves when their value
+ * lies in [0.25, 4] -- the only range in which the two sums can fall on different sides of the threshold -- so the
+ * `<= 1` decision they support is always the reference's. */
+int lumahip_mean_luminance_reference_device(lumahip_ctx *ctx, const float *rgb_dev, unsigned w, unsigned h, float sc,
+                                            float *mean_host);
+
 /* array quantize / dequantize on device-resident values (asynchronous on the context's stream) */
 int lumahip_quantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);
 int lumahip_dequantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);

@@ -770,6 +770,57 @@ __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
     }
 }
 
+// ---- the reference's mean luminance, exactly ---------------------------------------------------------
+// LumaEncoder::setVpxChannel accumulates plane 0 into ONE fp32 variable in raster order (src/luma_encoder.cpp:276,294,314)
+// and warns when avg / (w*h) <= 1.  A sequential fp32 sum is not associative: the encode kernels' per-frame statistics
+// (tree / atomic order) give a more accurate but different number, typically 1e-4 relative apart at 4K.  When the caller
+// needs the reference's value -- the host entry points do when the fast mean is within 1 % of the threshold -- these two
+// kernels reproduce it: k_channel0 writes the transformed channel 0 of one frame, k_seq_sum adds it up in the reference's
+// order (one wave; lanes load 64 consecutive values at a time, the adds run lane-uniformly in raster order; ~25 ms at 4K).
+template <int CS>
+__global__ __launch_bounds__(256) void k_channel0(const float *src, size_t chan_stride, size_t n, float sc, float Lmax, float *out)
+{
+    __shared__ PowfTables s_pw;
+    if constexpr (CS == CS_YCBCR) {
+        const double lt[16][2] = LH_POWF_LOG2_TAB;
+        const uint64_t et[32] = LH_POWF_EXP2_TAB;
+        if (threadIdx.x < 16) {
+            s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
+            s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
+        }
+        if (threadIdx.x < 32)
+            s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+        __syncthreads();
+    }
+    const XformConst k = make_xform_const<CS>(sc, Lmax, &s_pw);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float c0, c1, c2;
+        xform_fwd<CS>(src[i] * sc, src[i + chan_stride] * sc, src[i + 2 * chan_stride] * sc, k, c0, c1, c2);
+        out[i] = c0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_seq_sum(const float *x, size_t n, float *out)
+{
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    for (size_t base = 0; base < n; base += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const size_t idx = base + (size_t)j * 64 + lane;
+            v[j] = idx < n ? x[idx] : 0.0f;  // acc + 0.0f == acc
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 64; i++)
+                acc = acc + __shfl(v[j], i, 64);
+    }
+    if (lane == 0)
+        out[0] = acc;
+}
+
 // ---- array quantize / dequantize (LumaQuantizer::quantize / dequantize over arrays) ----------------
 struct QArrArgs {
     QuantDev q;

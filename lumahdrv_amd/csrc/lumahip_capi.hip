@@ -808,6 +808,65 @@ static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, co
     L.total = off;
 }
 
+// sequential fp32 sum of n device floats / (w*h), as the reference forms its mean luminance (see k_seq_sum)
+static int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned h, float *mean_host)
+{
+    const size_t n = (size_t)w * h;
+    if (!c->d_stats)
+        HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, c->stream, chan0_dev, n, c->d_stats);
+    HIPCHK(c, hipGetLastError());
+    float sum = 0.0f;
+    HIPCHK(c, hipMemcpyAsync(&sum, c->d_stats, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mean_host = sum / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
+    return LUMAHIP_OK;
+}
+
+// mean of transformed channel 0 of ONE device-resident (untransformed) frame, summed exactly as the reference does
+static int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc, int cs_eff,
+                                         float *mean_host)
+{
+    const size_t n = (size_t)w * h;
+    int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, n * sizeof(float));
+    if (rc)
+        return rc;
+    void (*kern)(const float *, size_t, size_t, float, float, float *) = nullptr;
+    switch (cs_eff) {
+    case CS_LUV: kern = k_channel0<CS_LUV>; break;
+    case CS_RGB: kern = k_channel0<CS_RGB>; break;
+    case CS_YCBCR: kern = k_channel0<CS_YCBCR>; break;
+    case CS_XYZ: kern = k_channel0<CS_XYZ>; break;
+    case CS_PACK: kern = k_channel0<CS_PACK>; break;
+    }
+    if (!kern)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", cs_eff);
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, rgb_dev, n, n, sc, c->q.Lmax, c->d_arr);
+    return seq_mean(c, c->d_arr, w, h, mean_host);
+}
+
+extern "C" int lumahip_mean_luminance_reference_device(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc,
+                                                       float *mean_host)
+{
+    if (!c || !rgb_dev || !mean_host || w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    return mean_luminance_reference_impl(c, rgb_dev, w, h, sc, c->q.cs, mean_host);
+}
+
+// The reference warns when its (sequentially summed) mean luminance is <= 1.  That fp32 sum is far from the true sum on
+// large frames: once the running sum S is large, addends below ulp(S)/2 vanish and the rest are rounded to multiples of
+// ulp(S) (measured: -0.2 % at 1080p, several % at 4K on wide-range content), whereas the kernels' statistic (per-wave
+// partial sums) is accurate to ~1e-6.  Around the threshold S stays below N * 4, i.e. ulp(S)/2 <= 2 up to 8K frames, so
+// the two can only disagree about `<= 1` when the accurate mean lies in [0.25, 4]: inside that band the host entry points
+// replace the statistic by the reference's exact value (k_seq_sum), outside it the decision is the same either way.
+static bool mean_near_threshold(float m) { return m >= 0.25f && m <= 4.0f; }
+
 static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
                                   unsigned char *const planes[3], const int stride[3], float *mean_lum,
                                   float *transformed_out, int cs_eff)
@@ -850,8 +909,12 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         HIPCHK(c, hipMemcpyAsync(transformed_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (mean_lum)
+    if (mean_lum) {
         *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
+        if (mean_near_threshold(*mean_lum))  // d_frame holds the caller's frame, or already its transformed version
+            return transformed_out ? seq_mean(c, c->d_frame, w, h, mean_lum)
+                                   : mean_luminance_reference_impl(c, c->d_frame, w, h, sc, cs_eff, mean_lum);
+    }
     return LUMAHIP_OK;
 }
 
@@ -1000,8 +1063,14 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     HIPCHK(c, hipStreamSynchronize(c->s_kern));
     HIPCHK(c, hipStreamSynchronize(c->s_d2h));
     if (rc == LUMAHIP_OK && mean_lum)
-        for (unsigned i = 0; i < nframes; i++)
+        for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
             mean_lum[i] = c->h_stats[3 * (size_t)i] / (float)((int)w * (int)h);
+            if (mean_near_threshold(mean_lum[i])) {  // rare: redo this frame's sum in the reference's order
+                if (hipMemcpyAsync(c->slot[0].d_frame, rgb[i], nfl * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+                    return fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+                rc = mean_luminance_reference_impl(c, c->slot[0].d_frame, w, h, sc, c->q.cs, &mean_lum[i]);
+            }
+        }
     return rc;
 }
 

@@ -569,3 +569,127 @@ def test_reference_loop_digests_on_gpu(L, oracle_mod, golden_dir):
         assert (o.survey_digest(o.packed_rows(planes[0], 2560)), o.survey_digest(o.packed_rows(planes[1], cb)),
                 o.survey_digest(o.packed_rows(planes[2], cb))) == (d["Y"], d["U"], d["V"])
         assert o.survey_digest(q.ctx.decode_frame(planes, st, 1280, 720, 1.0, profile)) == d["decoded"]
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_mean_luminance_against_the_references_sequential_sum(L, oracle_mod, w, h):
+    """LumaEncoder::setVpxChannel sums plane 0 sequentially in fp32 (src/luma_encoder.cpp:276,294,314) -- a sum that
+    drops small addends once it is large.  At full size: (a) the kernels' statistic is the ACCURATE mean (1e-5 of a
+    float64 sum) and therefore differs from the reference's number (documented in INTEGRATION.md); (b)
+    lumahip_mean_luminance_reference_device reproduces the reference's sequential sum bit for bit; (c) frames whose mean
+    lies anywhere near the warning threshold get that exact value from the host entry points, so the `avg <= 1`
+    decision is the reference's even where the two sums disagree."""
+    import torch
+    o = oracle_mod
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    f = o.synth_frame(w, h, frame=3)
+    g64 = f.copy()
+    orc.transform(g64, True, 1.0)
+    true_mean = float(g64[0].astype(np.float64).mean())
+    _, _, seq = orc.encode(f.copy(), 1.0, 2, threads=1)             # the reference's order
+    _, _, fast = q.ctx.encode_frame(f, 1.0, 2)
+    assert abs(fast - true_mean) <= 1e-5 * true_mean
+    assert abs(seq - true_mean) > 1e-4 * true_mean                  # the reference's own sum is the inaccurate one
+    d = torch.from_numpy(f).cuda()
+    exact = q.ctx.mean_luminance_reference_device(d.data_ptr(), w, h, 1.0)
+    assert np.float32(exact) == np.float32(seq)
+    # frames around the threshold: accurate mean 0.9 ... 1.3; the sequential sum may land on the other side of 1.0
+    sides = set()
+    for target in (0.9, 0.99995, 1.00005, 1.05, 1.3):
+        g = (f * np.float32(target / true_mean)).astype(np.float32)
+        _, _, seq_g = orc.encode(g.copy(), 1.0, 2, threads=1)
+        _, _, host = q.ctx.encode_frame(g, 1.0, 2)
+        assert np.float32(host) == np.float32(seq_g)                  # exact, hence the same `avg <= 1.0f` decision
+        sides.add((target > 1.0, seq_g > 1.0))
+        if target in (0.99995, 1.05):
+            _, _, host_b = q.ctx.encode_frames([g, f], 1.0, 2)        # the pipelined batch entry point too
+            assert np.float32(host_b[0]) == np.float32(seq_g) and abs(host_b[1] - true_mean) <= 1e-5 * true_mean
+            qf = L.LumaQuantizer()
+            qf.setQuantizer(*CONFIGS["pq11_luv8"])
+            _, _, host_t, _ = qf.ctx.encode_frame(g, 1.0, 2, want_transformed=True)   # the facade's call shape
+            assert np.float32(host_t) == np.float32(seq_g)
+    assert len(sides) >= 2
+
+
+def test_fast_division_forms_equal_ieee_division_build(L, oracle_mod, tmp_path):
+    """The kernels use shortened division sequences where operand ranges license them (div_nr / div_255_pos / div_219_fin,
+    luma_device.hpp).  A second build of the same library with -DLH_NO_FAST_DIV (every division through the compiler's
+    full IEEE sequence; lumahdrv_amd/lib_nofastdiv, built by __graft_entry__.build()) must produce identical planes and
+    floats on inputs chosen to sit on the range edges: X, Y, Z at / beyond the 1e-4 and 1e8 clamps in every mix, zero /
+    huge / non-finite components, chroma codes 0, 1, maxC, out of range, luminance codes at the table ends, PQ peaks
+    Lmax = 1e-6 and 1e9 for the YCbCr path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "lumahdrv_amd", "lib_nofastdiv", "liblumahip.so")
+    if not os.path.exists(alt):
+        from lumahdrv_amd import capi
+        capi.build_library(nofastdiv=True)
+    vals = np.array([0, 1e-7, 1e-4, 3e-4, 1, 97.0, 1e4, 9e7, 1e8, 4e8, 1e12, 8e37, np.inf, np.nan, -1.0], dtype=np.float32)
+    r, g, b = np.meshgrid(vals, vals, vals, indexing="ij")
+    edge = np.stack([r.ravel(), g.ravel(), b.ravel()])                 # 3375 pixels
+    n = edge.shape[1] + (-edge.shape[1]) % 64
+    frame = np.ones((3, n), dtype=np.float32)
+    frame[:, :edge.shape[1]] = edge
+    frame = frame.reshape(3, -1, 64)[:, : (frame.size // 3 // 64) // 2 * 2].copy()   # even height
+    rng = np.random.default_rng(9)
+    wide = np.exp(rng.uniform(np.log(1e-9), np.log(1e10), size=(3, 64, 64))).astype(np.float32)
+    np.savez(tmp_path / "in.npz", edge=frame, wide=wide)
+    worker = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import lumahdrv_amd as L
+d = np.load(sys.argv[1])
+out = {}
+cfgs = {"luv": (1, 11, 0, 8, 1e4, 0.005), "xyz": (4, 12, 3, 8, 1e4, 0.005), "rgb": (1, 12, 1, 8, 1e4, 0.005),
+        "ycc": (1, 10, 2, 10, 1000.0, 0.01), "ycc_lo": (1, 10, 2, 10, 1e-6, 0.01), "ycc_hi": (1, 10, 2, 10, 1e9, 0.01)}
+for name, cfg in cfgs.items():
+    q = L.LumaQuantizer(); q.setQuantizer(*cfg)
+    for fname in ("edge", "wide"):
+        f = d[fname]
+        hh, ww = f.shape[1:]
+        for sc in (1.0, 20.0, 0.25):
+            for profile in (2, 3):
+                planes, st, _ = q.ctx.encode_frame(f, sc, profile)
+                for p in range(3):
+                    out["%%s_%%s_%%g_%%d_p%%d" %% (name, fname, sc, profile, p)] = planes[p]
+                # decode what was encoded, plus every code combination at the range edges
+                out["%%s_%%s_%%g_%%d_dec" %% (name, fname, sc, profile)] = q.ctx.decode_frame(planes, st, ww, hh, sc, profile)
+    maxv, maxc = 2 ** cfg[1] - 1, 2 ** cfg[3] - 1
+    lum = np.array([0, 1, maxv // 2, maxv - 1, maxv, maxv + 1, 65535], dtype=np.uint16)
+    chr_ = np.array([0, 1, maxc // 2, maxc - 1, maxc, maxc + 1, 65535], dtype=np.uint16)
+    a, bb, cc = np.meshgrid(lum, chr_, chr_, indexing="ij")
+    codes = [x.ravel() for x in (a, bb, cc)]
+    npx = codes[0].size + (-codes[0].size) %% 16
+    pl = []
+    for x in codes:
+        y = np.zeros(npx, dtype="<u2"); y[:x.size] = x
+        pl.append(y.reshape(-1, 8).view(np.uint8).copy())
+    hh, ww = pl[0].shape[0], 8
+    hh -= hh %% 2
+    pl = [p_[:hh] for p_ in pl]
+    for sc in (1.0, 20.0):
+        out["%%s_codes_%%g" %% (name, sc)] = q.ctx.decode_frame(pl, (16, 16, 16), ww, hh, sc, 3)
+np.savez(sys.argv[2], **out)
+from lumahdrv_amd import capi
+print("LIB", capi.library_path())
+""" % (root,)
+    outs = {}
+    for tag, lib in (("fast", None), ("ieee", alt)):
+        env = dict(os.environ)
+        if lib:
+            env["LUMAHIP_LIB"] = lib
+        else:
+            env.pop("LUMAHIP_LIB", None)
+        p = subprocess.run([sys.executable, "-c", worker, str(tmp_path / "in.npz"), str(tmp_path / (tag + ".npz"))],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert ("lib_nofastdiv" in p.stdout) == (lib is not None), p.stdout       # the build that was asked for was loaded
+        outs[tag] = np.load(tmp_path / (tag + ".npz"))
+    assert set(outs["fast"].files) == set(outs["ieee"].files) and len(outs["fast"].files) >= 300
+    for k in outs["fast"].files:
+        a, b_ = outs["fast"][k], outs["ieee"][k]
+        if a.dtype == np.float32:
+            assert same_bits(a, b_), k
+        else:
+            assert np.array_equal(a, b_), k
