@@ -69,6 +69,10 @@ public:
     LumaDecoderParams getParams() { return m_params; }
     void setParams(LumaDecoderParams params) { m_params = params; }
 
+    // the reference returns its MkvInterface here (luma_decoder.h:113 there; lumaplay.cpp:200,443 ask it for
+    // getDuration() / getFrameDuration()); this build's upstream stage is a LumaPlaneSource with the same two queries
+    LumaPlaneSource *getReader() { return m_source; }
+
     // ---- additions ----
     void setSource(LumaPlaneSource *src) { m_source = src; }  // not owned; default: raw plane stream
 

@@ -54,6 +54,16 @@ public:
 
     // throws LumaException("Invalid frame size") for zero or odd dimensions, like the reference
     bool initialize(const char *outputFile, const unsigned int w, const unsigned int h, bool verbose = 0);
+    // LumaEncoderBase::initialize(outputFile, w, h, ma, mi, verbose) of the reference (luma_encoder.h:88-96 there) opens
+    // the container with a luminance range; here the range goes where the container would record it: the parameters
+    // behind attachment 436 and the quantizer
+    bool initialize(const char *outputFile, const unsigned int w, const unsigned int h, const float ma, const float mi,
+                    bool verbose = 0)
+    {
+        m_params.maxLum = ma;
+        m_params.minLum = mi;
+        return initialize(outputFile, w, h, verbose);
+    }
     bool run();
     // quantize + pack an ALREADY colour-transformed frame (what the reference's setChannels expects)
     void setChannels(LumaFrame *frame);

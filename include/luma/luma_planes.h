@@ -72,6 +72,10 @@ public:
     // next frame's planes (valid until the next call); false at end of stream
     virtual bool readFrame(const LumaPlanes **img) = 0;
     virtual bool seekToFrame(unsigned int index) = 0;
+    // what the reference's player asks its MkvInterface through LumaDecoder::getReader() (lumaplay.cpp:200,443):
+    // stream duration and the duration of one frame, in seconds; 0 when unknown
+    virtual float getDuration() { return 0.0f; }
+    virtual float getFrameDuration() { return 0.0f; }
 };
 
 // Raw plane stream: "LHIPSTR1" | w h profile fps | n_attachments { id, desc, bytes } | frames (tight rows).
@@ -105,6 +109,8 @@ public:
     unsigned int width() const { return m_w; }
     unsigned int height() const { return m_h; }
     float fps() const { return m_fps; }
+    float getDuration();
+    float getFrameDuration() { return m_fps > 0.0f ? 1.0f / m_fps : 0.0f; }
 
 private:
     FILE *m_f;

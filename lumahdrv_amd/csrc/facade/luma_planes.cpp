@@ -192,6 +192,18 @@ bool LumaRawStreamReader::readFrame(const LumaPlanes **img)
     return true;
 }
 
+float LumaRawStreamReader::getDuration()
+{
+    if (!m_f || !m_frameBytes || !(m_fps > 0.0f))
+        return 0.0f;
+    const long here = ftell(m_f);
+    float d = 0.0f;
+    if (fseek(m_f, 0, SEEK_END) == 0)
+        d = (float)((size_t)(ftell(m_f) - m_dataStart) / m_frameBytes) / m_fps;
+    fseek(m_f, here, SEEK_SET);
+    return d;
+}
+
 bool LumaRawStreamReader::seekToFrame(unsigned int index)
 {
     if (!m_f)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "luma/luma_decoder.h"
 #include "luma/luma_encoder.h"
@@ -87,10 +88,23 @@ int main(int argc, char **argv)
             n++;
         }
         printf("Decoding finished. %d frames decoded. size %u\n", n, decoder.getQuantizer()->getSize());
+        // what lumaplay asks the reader (lumaplay.cpp:200,443)
+        printf("reader %.6f %.6f\n", decoder.getReader()->getDuration(), decoder.getReader()->getFrameDuration());
         // per-value API (GPU one-element launches): PQ-11 pins of SURVEY.md 8(c) when the table is PQ-11
         LumaQuantizer *q = decoder.getQuantizer();
         printf("scalar %.9g %.9g %.9g %.9g\n", q->quantize(1.0f, 0), q->quantize(100.0f, 0), q->quantize(0.3f, 1),
                q->dequantize(307.0f, 0));
+        // LumaEncoderBase::initialize(file, w, h, ma, mi): the luminance range lands in attachment 436
+        {
+            LumaEncoder ranged;
+            ranged.initialize((std::string(path) + ".ranged").c_str(), 64, 32, 4000.0f, 0.02f);
+            LumaFrame tf;
+            lumaTestFrame(tf, 64, 32);
+            ranged.encode(&tf);
+            ranged.finish();
+            LumaDecoder rd((std::string(path) + ".ranged").c_str());
+            printf("ranged %.6g %.6g\n", rd.getParams().maxLum, rd.getParams().minLum);
+        }
         // error conventions
         try {
             LumaEncoder bad;

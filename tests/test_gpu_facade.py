@@ -42,6 +42,8 @@ def test_facade_roundtrip_matches_oracle(oracle_mod, tmp_path, cs, bits, profile
     dec = orc.decode(planes, st, w, h, 1.0, profile)
     assert got["decoded"].split()[0] == "%016x" % o.fnv1a64(dec)
     assert "3 frames decoded" in r.stdout and "size %d" % ((1 << bits) - 1) in r.stdout
+    assert got["reader"].split() == ["0.120000", "0.040000"]      # 3 frames at 25 fps, getReader()->getDuration() / getFrameDuration()
+    assert got["ranged"].split() == ["4000", "0.02"]              # initialize(file, w, h, ma, mi)
     assert got["odd-size:"] == "Invalid frame size"             # src/luma_encoder.cpp:118-119
     sc = [float(x) for x in got["scalar"].split()]
     exp = [orc.quantize(1.0, 0), orc.quantize(100.0, 0), orc.quantize(0.3, 1), orc.dequantize(307.0, 0)]
@@ -118,3 +120,103 @@ def test_stream_metadata_matches_the_reference_attachments(oracle_mod, tmp_path)
     assert struct.unpack("<2f", att[436]) == (np.float32(1e4), np.float32(0.005))
     frame_bytes = 64 * 32 * 2 + 2 * 32 * 16 * 2
     assert len(d) - p == frame_bytes                                  # one frame of tight 4:2:0 16-bit planes
+
+
+def _parse_lhs(path):
+    import struct
+    d = open(path, "rb").read()
+    assert d[:8] == b"LHIPSTR1"
+    w, h, prof = struct.unpack_from("<III", d, 8)
+    fps = struct.unpack_from("<f", d, 20)[0]
+    natt = struct.unpack_from("<I", d, 24)[0]
+    p = 28
+    att = {}
+    for _ in range(natt):
+        aid, dl = struct.unpack_from("<II", d, p)
+        p += 8 + dl
+        sz = struct.unpack_from("<I", d, p)[0]
+        att[aid] = d[p + 4:p + 4 + sz]
+        p += 4 + sz
+    return w, h, prof, fps, att, d[p:]
+
+
+def _split_planes(body, w, h, profile, index):
+    sub, bps = profile in (0, 2), (2 if profile > 1 else 1)
+    cw, chh = (w // 2, h // 2) if sub else (w, h)
+    sizes = [w * h * bps, cw * chh * bps, cw * chh * bps]
+    off = index * sum(sizes)
+    out = []
+    for s, (pw, ph) in zip(sizes, ((w, h), (cw, chh), (cw, chh))):
+        out.append(np.frombuffer(body[off:off + s], dtype=np.uint8).reshape(ph, pw * bps))
+        off += s
+    return out
+
+
+@pytest.mark.gpu
+def test_lumaenc_lumadec_drivers_end_to_end(oracle_mod, tmp_path):
+    """tools/lumaenc + tools/lumadec (counterparts of the reference's lumaenc.cpp / lumadec.cpp) on the GPU:
+    (1) `-i __test__ -f 1:2` with default parameters reproduces the SURVEY 8(c) Y/U/V digests of testFrame 1280x720;
+    (2) every hot-path flag reaches the kernels: LOG 12-bit, 10-bit chroma, profile 3, pre-scaling, luminance range,
+        frame rate -- planes and attachments 430-436 against the oracle configured the same way;
+    (3) EXR pattern input (two 1920x1080 frames = BASELINE configs[0] size, half-float files) with start:step:end, then
+        lumadec back to EXR, against the oracle on the half-rounded frames."""
+    import struct
+    import lumahdrv_amd
+    lumahdrv_amd.build_library()
+    o = oracle_mod
+    bind = os.path.join(ROOT, "lumahdrv_amd", "bin")
+    enc, dec = os.path.join(bind, "lumaenc"), os.path.join(bind, "lumadec")
+    # (1)
+    s1 = str(tmp_path / "t.lhs")
+    r = subprocess.run([enc, "-i", "__test__", "-f", "1:2", "-o", s1], capture_output=True, text=True)
+    assert r.returncode == 0 and "Encoding finished. 2 frames encoded." in r.stderr, r.stderr
+    w, h, prof, fps, att, body = _parse_lhs(s1)
+    assert (w, h, prof, fps) == (1280, 720, 2, 25.0) and len(body) == 2 * (1280 * 720 * 2 + 2 * 640 * 360 * 2)
+    pl = _split_planes(body, w, h, prof, 1)
+    assert [o.survey_digest(p) for p in pl] == ["e0ff09731298e8f6", "4c410839cf4228cc", "28868357f4a5e5e5"]
+    # (2)
+    s2 = str(tmp_path / "u.lhs")
+    r = subprocess.run([enc, "--input", "__test__", "--frames", "7:7", "--output", s2, "--transfer-function", "LOG",
+                        "--ptf-bitdepth", "12", "--color-space", "LUV", "--color-bitdepth", "10", "--profile", "3",
+                        "--pre-scaling", "2.5", "--max-luminance", "5000", "--min-luminance", "0.01", "--framerate", "50",
+                        "-b", "500", "-q", "7", "-k", "12", "-eb", "10", "-l", "-v"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Encoding frame 7... done" in r.stderr, r.stderr
+    w, h, prof, fps, att, body = _parse_lhs(s2)
+    assert (w, h, prof, fps) == (1280, 720, 3, 50.0)
+    assert struct.unpack("<I", att[430])[0] == 12 and struct.unpack("<I", att[431])[0] == 10
+    assert struct.unpack("<i", att[432])[0] == o.PTF_LOG and struct.unpack("<i", att[433])[0] == o.CS_LUV
+    assert struct.unpack("<f", att[435])[0] == 2.5 and struct.unpack("<2f", att[436]) == (5000.0, np.float32(0.01))
+    orc = o.Oracle(o.PTF_LOG, 12, o.CS_LUV, 10, 5000.0, 0.01)
+    planes, st, _ = orc.encode(o.test_frame(1280, 720), 2.5, 3)
+    for a, b in zip(_split_planes(body, w, h, prof, 0), planes):
+        assert np.array_equal(a, b[:, :a.shape[1]])
+    # (3)
+    from tests.test_exr import read_exr_py, write_exr_py
+    frames = {}
+    for idx in (3, 5):
+        f = o.synth_frame(1920, 1080, frame=idx)
+        with np.errstate(over="ignore"):
+            frames[idx] = f.astype(np.float16)
+        write_exr_py(str(tmp_path / ("in_%04d.exr" % idx)), {n: frames[idx][i] for i, n in enumerate("RGB")}, 3)
+    s3 = str(tmp_path / "v.lhs")
+    r = subprocess.run([enc, "-i", str(tmp_path / "in_%04d.exr"), "-f", "3:2:5", "-o", s3], capture_output=True, text=True)
+    assert r.returncode == 0 and "2 frames encoded" in r.stderr, r.stderr
+    w, h, prof, fps, att, body = _parse_lhs(s3)
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    enc_planes = []
+    for k, idx in enumerate((3, 5)):
+        planes, st, _ = orc.encode(frames[idx].astype(np.float32), 1.0, 2)
+        enc_planes.append((planes, st))
+        for a, b in zip(_split_planes(body, w, h, prof, k), planes):
+            assert np.array_equal(a, b[:, :a.shape[1]])
+    r = subprocess.run([dec, "-i", s3, "-o", str(tmp_path / "out_%02d.exr")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Decoding finished. 2 frames decoded." in r.stderr, r.stderr
+    for k in (0, 1):
+        ch, _ = read_exr_py(str(tmp_path / ("out_%02d.exr" % (k + 1))))
+        d = orc.decode(enc_planes[k][0], enc_planes[k][1], 1920, 1080, 1.0, 2)
+        with np.errstate(over="ignore"):
+            for i, n in enumerate("RGB"):
+                assert np.array_equal(ch[n].view(np.uint32), d[i].astype(np.float16).astype(np.float32).view(np.uint32)), (k, n)
+    # a missing frame file ends the run the way the reference's does: an encoding error, exit status 1
+    r = subprocess.run([enc, "-i", str(tmp_path / "in_%04d.exr"), "-f", "3:1:5", "-o", str(tmp_path / "w.lhs")], capture_output=True, text=True)
+    assert r.returncode == 1 and "lumaenc encoding error:" in r.stderr

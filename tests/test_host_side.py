@@ -138,3 +138,45 @@ def test_raw_stream_reader_rejects_crafted_headers(L, tmp_path):
                     "-Wl,-rpath," + lib], check=True)
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_lumaenc_lumadec_option_handling(L):
+    """tools/lumaenc.cpp / lumadec.cpp: the reference's option names, ranges, value sets and error situations
+    (lumaenc.cpp:106-179, lumadec.cpp:71-90, its ArgParser): every rejected command line exits with status 1 and the
+    reference's '<tool> input error:' prefix.  CPU only: nothing here reaches the GPU."""
+    enc = os.path.join(ROOT, "lumahdrv_amd", "bin", "lumaenc")
+    dec = os.path.join(ROOT, "lumahdrv_amd", "bin", "lumadec")
+    assert os.path.exists(enc) and os.path.exists(dec)
+
+    def run(exe, *a):
+        r = subprocess.run([exe] + list(a), capture_output=True, text=True, timeout=60)
+        return r.returncode, r.stderr
+
+    rc, err = run(enc, "--help")
+    assert rc == 1 and "--transfer-function <string>" in err and "-eb <int>," in err
+    for flags, msg in (
+            ((), "Missing required option '--output'"),
+            (("-o", "x.lhs", "--bogus"), "The argument '--bogus' is not a valid input option"),
+            (("-o",), "No value provided for input option '-o'"),
+            (("-o", "x.mkv"), "Unsupported output format"),
+            (("-o", "x.lhs", "-p", "4"), "Argument '-p' with value '4' is out of range. Valid range is [0, 3]"),
+            (("-o", "x.lhs", "--quantizer-scaling", "64"), "Valid range is [0, 63]"),
+            (("-o", "x.lhs", "-pb", "17"), "Valid range is [0, 16]"),
+            (("-o", "x.lhs", "-ma", "50"), "Argument '-ma' with value '50' is out of range. Valid range is [100, 100000]"),
+            (("-o", "x.lhs", "-mi", "100"), "out of range"),
+            (("-o", "x.lhs", "-b", "10000"), "Valid range is [0, 9999]"),
+            (("-o", "x.lhs", "-eb", "9"), "Input '9' for argument '-eb' is not valid. Valid values are: 8 10 12"),
+            (("-o", "x.lhs", "-ptf", "pq"), "Input 'pq' for argument '-ptf' is not valid. Valid values are: PSI PQ LOG HDRVDP LINEAR"),
+            (("-o", "x.lhs", "-cs", "YUV"), "Valid values are: LUV RGB YCBCR XYZ"),
+            (("-o", "x.lhs", "-i", "__test__", "-f", "5"), "Unable to parse frame range from '5'. Valid format is startframe:step:endframe"),
+            (("-o", "x.lhs", "-i", "__test__", "-f", "1:2:3:4"), "Unable to parse frame range"),
+            (("-o", "x.lhs", "-i", "__test__", "-f", "a:3"), "Unable to parse frame range"),
+            (("-o", "x.lhs", "-i", "__test__", "-f", "9:1:3"), "Invalid frame range '9:1:3'. End frame should be >= start frame")):
+        rc, err = run(enc, *flags)
+        assert rc == 1 and "lumaenc input error: " in err and msg in err, (flags, err)
+    rc, err = run(enc, "-o", "x.lhs")                       # no input: the reference needs pfstools for stdin streams
+    assert rc == 1 and "lumaenc encoding error: Compiled without pfstools support" in err
+    rc, err = run(dec)
+    assert rc == 1 and "lumadec input error: Missing required option '--input'" in err
+    rc, err = run(dec, "-i", "/nonexistent/stream.lhs")
+    assert rc == 1 and "lumadec decoding error: " in err
