@@ -449,6 +449,28 @@ LH_DEV LuvChroma luv_chroma(float c1, float c2)
     return o;
 }
 
+// The same factors from u = uv_table[code1], v = uv_table[code2], where the decode kernels' LDS table holds
+// (max(code/maxC, 1e-10) * 255) / 410 for every code 0..maxC, computed with IEEE division when the table is staged
+// (stage_tables): the two dequantisations and the two divisions by 410 become two LDS reads.  u, v in [6e-11, 0.63] as in
+// luv_chroma<true>, so the remaining divisions take the short path under the same licence.
+LH_DEV LuvChroma luv_chroma_uv(float u, float v)
+{
+    LuvChroma o;
+    const float d = ((6.0f * u) - 16.0f * v) + 12.0f;
+    const float rd = rcp_nr(d);
+    const float x = div_nr_r(9.0f * u, d, rd);
+    const float y = div_nr_r(4.0f * v, d, rd);
+    const float ry = rcp_nr(y);
+    o.xy = div_nr_r(x, y, ry);
+    o.zy = div_nr_r((1.0f - x) - y, y, ry);
+    return o;
+}
+
+LH_DEV float uv_table_entry(int code, float maxC)
+{
+    return div_ieee(std_max(div_ieee((float)code, maxC), 1e-10f) * 255.0f, 410.0f);  // src/luma_quantizer.cpp:261,405-406
+}
+
 LH_DEV void luv_apply(float L, const LuvChroma &q, float &r, float &g, float &b)
 {
     const float Y = clamp_xyz(L);

@@ -70,9 +70,10 @@ struct DecArgs {
 };
 
 // LDS layout: [powf tables (YCbCr only; FIRST, so that their addresses are immediates in the powf chains)]
-// [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B].
+// [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B]
+// [u'v' table: maxC+1 floats (Lu'v' decode only), see luv_chroma_uv].
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
-enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8 };
+enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16 };
 
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
 LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
@@ -113,6 +114,13 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q)
         uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
         for (int i = tid; i < b4; i += nt)
             sb[i] = gb[i];
+    }
+    if constexpr (WHAT & STAGE_UV) {
+        static_assert(WHAT & STAGE_LUT, "the u'v' table sits behind the luminance table");
+        float *uv = reinterpret_cast<float *>(smem + off + lds_lut_bytes(q));
+        const int n = (int)q.maxC + 1;
+        for (int i = tid; i < n; i += nt)
+            uv[i] = uv_table_entry(i, q.maxC);
     }
     __syncthreads();
 }
@@ -566,8 +574,8 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
-template <int CS, bool SUB, int VW, bool DISP, typename LutPtr>
-LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, size_t cs)
+template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, typename LutPtr>
+LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, const float *s_uv, size_t cs)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
     const float maxC = a.q.maxC;
@@ -605,10 +613,14 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
         LuvChroma ch[NC];
 #pragma unroll
         for (int j = 0; j < NC; j++) {
-            if (u.c1[j] <= maxCi && u.c2[j] <= maxCi)
-                ch[j] = luv_chroma<true>(dequantize_color_safe(u.c1[j], maxC, rmaxC), dequantize_color_safe(u.c2[j], maxC, rmaxC));
-            else
+            if (u.c1[j] <= maxCi && u.c2[j] <= maxCi) {
+                if constexpr (UVTAB)
+                    ch[j] = luv_chroma_uv(s_uv[u.c1[j]], s_uv[u.c2[j]]);
+                else
+                    ch[j] = luv_chroma<true>(dequantize_color_safe(u.c1[j], maxC, rmaxC), dequantize_color_safe(u.c2[j], maxC, rmaxC));
+            } else {
                 ch[j] = luv_chroma<false>(dequantize_color(u.c1[j], maxC), dequantize_color(u.c2[j], maxC));
+            }
         }
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -694,9 +706,12 @@ template <int CS, bool SUB, int VW, bool GL, bool DISP = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0);
+    // GL: transfer-function table or chroma depth beyond 12 bits -- tables stay in global memory / are not built
+    constexpr bool UVTAB = (CS == CS_LUV && !GL);
+    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0);
     stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
+    const float *s_uv = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_lut_bytes(a.q));
     const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTables *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -710,9 +725,9 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         if (cur.valid) {
             if constexpr (GL)
-                dec_process<CS, SUB, VW, DISP>(cur, a, k, a.q.lut, cs);
+                dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv, cs);
             else
-                dec_process<CS, SUB, VW, DISP>(cur, a, k, s_lut, cs);
+                dec_process<CS, SUB, VW, DISP, UVTAB>(cur, a, k, s_lut, s_uv, cs);
         }
         cur = nxt;
     }

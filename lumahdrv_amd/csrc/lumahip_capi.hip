@@ -217,8 +217,8 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     // (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table)
     // runs the reference's bisection literally.  LUMAHIP_FORCE_LITERAL is the tests' hook for that path.
     c->tix = ThreshIndex();
-    c->lut_in_lds = (n <= 4096);
-    int mode = c->lut_in_lds ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
+    c->lut_in_lds = (n <= 4096 && bitdepthC <= 12);  // decode side: luminance table (+ Lu'v' chroma table) staged in LDS
+    int mode = n <= 4096 ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
     if (!getenv("LUMAHIP_FORCE_LITERAL")) {
         c->tix = build_thresh_index(lut, (int)n, 1 << 19);
         if (c->tix.ok)
@@ -292,6 +292,8 @@ static size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
             b += ((size_t)q.nbuckets * 4 + 15) & ~(size_t)15;
     } else if (c->lut_in_lds) {
         b += lut_b;
+        if (cs_eff == CS_LUV)
+            b += (((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15;  // u'v' table of the Lu'v' decode kernels
     }
     if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTables);
