@@ -4,6 +4,7 @@ links, and without a GPU every compute entry point fails loudly (no CPU fallback
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -180,3 +181,27 @@ def test_lumaenc_lumadec_option_handling(L):
     assert rc == 1 and "lumadec input error: Missing required option '--input'" in err
     rc, err = run(dec, "-i", "/nonexistent/stream.lhs")
     assert rc == 1 and "lumadec decoding error: " in err
+
+
+def test_integration_examples_compile_against_the_reference(tmp_path):
+    """INTEGRATION.md's two ways in are real code, compiled here against the reference tree (build container only):
+    A. tools/integration/vpx_mkv_sink.h -- the reference's libvpx + MkvInterface stages as a LumaPlaneSink;
+    B. tools/integration/apply_patch_b.py -- the reference's own luma_encoder / luma_decoder sources with their two hot
+       loops replaced by C-ABI calls.  (Compile-only: libvpx itself is not built in this image.)"""
+    ref = "/root/reference"
+    vpx = os.path.join(ROOT, "oracle", "_ref", "vpx_hdr")
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("needs /root/reference")
+    if not os.path.isdir(os.path.join(vpx, "vpx")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_planes"], check=True)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ref, "include", "luma"), "-I" + os.path.join(ref, "lib", "ebml"),
+           "-I" + os.path.join(ref, "lib", "matroska"), "-I" + os.path.join(vpx, "vpx"), "-I" + vpx]
+    src = tmp_path / "sink_check.cpp"
+    src.write_text('#include "vpx_mkv_sink.h"\nint main() { LumaEncoderParams p; VpxMkvSink s(p); LumaEncoder e; e.setSink(&s); return 0; }\n')
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "tools", "integration")] + inc + [str(src)], check=True)
+    out = tmp_path / "patch_b"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "integration", "apply_patch_b.py"), ref, str(out)], check=True)
+    for f in ("luma_encoder.cpp", "luma_decoder.cpp"):
+        # the patched headers shadow the reference's; everything else comes from the reference tree
+        subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I" + str(out), "-I" + os.path.join(ref, "include")] + inc + [str(out / f)], check=True)
+        assert "lumahip_" in (out / f).read_text() or "lumahip_" in (out / f.replace(".cpp", ".h")).read_text()
