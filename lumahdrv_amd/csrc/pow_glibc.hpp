@@ -244,10 +244,14 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
     const uint64_t ki = pw_asuint64(kd);
     kd -= SHIFT;
     const double rr = ylogx - kd;
-    // t = tab[ki % 32] + (ki << 47): the low 32 bits of ki << 47 are zero, so only the high word changes
+    // s = bits(tab[ki % 32] + (ki << 47)): the low 32 bits of ki << 47 are zero, so only the high word changes -- one
+    // 32-bit shift-add on the device (the compiler otherwise builds the 64-bit shift and add out of five instructions)
     const uint64_t t0 = T.exp2_tab[ki % 32];
-    const uint64_t t = ((uint64_t)((uint32_t)(t0 >> 32) + ((uint32_t)ki << 15)) << 32) | (uint32_t)t0;
-    const double s = pw_asdouble(t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double s = __hiloint2double((int)((uint32_t)(t0 >> 32) + ((uint32_t)ki << 15)), (int)(uint32_t)t0);
+#else
+    const double s = pw_asdouble(t0 + (ki << (52 - 5)));
+#endif
     const double zz = __builtin_fma(C0, rr, C1);
     const double rr2 = rr * rr;
     double e = __builtin_fma(C2, rr, 1.0);
