@@ -4,7 +4,8 @@
 // A self-contained reader / writer for the subset of OpenEXR the reference's I/O path uses
 // (src/exr_interface.cpp:73-187 goes through Imf::RgbaInputFile / RgbaOutputFile):
 //   * single-part scan-line files, channels named R, G, B, A of type HALF, FLOAT or UINT, sampling 1;
-//   * compression NONE, RLE, ZIPS, ZIP (PIZ / PXR24 / B44 / DWA files are rejected with a LumaException);
+//   * compression NONE, RLE, ZIPS, ZIP, PIZ, PXR24 on read (B44 / DWA files are rejected with a LumaException);
+//     PIZ / PXR24 are validated against an independent Python restatement only (no OpenEXR in the build image);
 //   * pixels pass through HALF exactly as Imf::Rgba does: FLOAT channels are rounded to half
 //     (round-to-nearest-even, overflow to infinity) on read, and writeFrame stores HALF R,G,B (WRITE_RGB);
 //   * channel handling as the reference: RGB / RGBA -> three planes; a file with only R, only G or only B
@@ -20,7 +21,8 @@
 
 class ExrInterface {
 public:
-    enum Compression { NO_COMPRESSION = 0, RLE_COMPRESSION = 1, ZIPS_COMPRESSION = 2, ZIP_COMPRESSION = 3 };
+    // OpenEXR's numbering; writeFrame produces 0..3, readFrame additionally decodes PIZ and PXR24
+    enum Compression { NO_COMPRESSION = 0, RLE_COMPRESSION = 1, ZIPS_COMPRESSION = 2, ZIP_COMPRESSION = 3, PIZ_COMPRESSION = 4, PXR24_COMPRESSION = 5 };
 
     static bool readFrame(const char *inputFile, LumaFrame &frame);
     static bool writeFrame(const char *outputFile, LumaFrame &frame);

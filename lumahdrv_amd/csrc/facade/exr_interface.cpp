@@ -1,6 +1,7 @@
 // exr_interface.cpp -- minimal OpenEXR scan-line reader / writer (see include/exr_interface.h).
 // File format per the OpenEXR file layout specification; no OpenEXR code or headers involved.
 #include "../../../include/exr_interface.h"
+#include "exr_codecs.h"
 
 #include <zlib.h>
 
@@ -208,7 +209,8 @@ bool ExrInterface::readFrame(const char *inputFile, LumaFrame &frame)
 static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
 {
     const int NO_COMPRESSION = ExrInterface::NO_COMPRESSION, RLE_COMPRESSION = ExrInterface::RLE_COMPRESSION,
-              ZIP_COMPRESSION = ExrInterface::ZIP_COMPRESSION;
+              ZIP_COMPRESSION = ExrInterface::ZIP_COMPRESSION, PIZ_COMPRESSION = ExrInterface::PIZ_COMPRESSION,
+              PXR24_COMPRESSION = ExrInterface::PXR24_COMPRESSION;
     const Bytes data = slurp(inputFile);
     Reader rd(data);
     if (rd.i32() != 20000630)
@@ -260,8 +262,8 @@ static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
     }
     if (chans.empty() || !haveDW || compression < 0)
         throw LumaException("EXR: header lacks channels / dataWindow / compression");
-    if (compression > ZIP_COMPRESSION)
-        throw LumaException("EXR: unsupported compression (only NONE, RLE, ZIPS and ZIP are implemented)");
+    if (compression > PXR24_COMPRESSION)
+        throw LumaException("EXR: unsupported compression (NONE, RLE, ZIPS, ZIP, PIZ and PXR24 are implemented; B44 / DWA are not)");
     const long W = (long)dw[2] - dw[0] + 1, H = (long)dw[3] - dw[1] + 1;
     if (W <= 0 || H <= 0 || W > 65536 || H > 65536)
         throw LumaException("EXR: bad data window");
@@ -310,7 +312,14 @@ static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
     if (!frame.init())
         throw LumaException("Cannot allocate memory for input frame");
 
-    const int linesPerBlock = (compression == ZIP_COMPRESSION) ? 16 : 1;
+    const int linesPerBlock = (compression == PIZ_COMPRESSION) ? 32 : (compression == ZIP_COMPRESSION || compression == PXR24_COMPRESSION) ? 16 : 1;
+    std::vector<lumaexr::ChannelLayout> layout;
+    for (size_t i = 0; i < chans.size(); i++) {
+        lumaexr::ChannelLayout cl;
+        cl.type = chans[i].type;
+        cl.bytes = chans[i].size();
+        layout.push_back(cl);
+    }
     const long nblocks = (H + linesPerBlock - 1) / linesPerBlock;
     std::vector<uint64_t> offsets((size_t)nblocks);
     for (long i = 0; i < nblocks; i++)
@@ -336,6 +345,14 @@ static bool readFrameImpl(const char *inputFile, LumaFrame &frame)
         } else if (compression == RLE_COMPRESSION) {
             rle_decode(payload, (size_t)dsz, tmp, expect);
             unpredict_interleave(tmp, raw);
+        } else if (compression == PIZ_COMPRESSION) {
+            lumaexr::piz_decode_block(payload, (size_t)dsz, layout, (int)W, (int)lines, raw);
+            if (raw.size() != expect)
+                throw LumaException("EXR: PIZ block has the wrong size");
+        } else if (compression == PXR24_COMPRESSION) {
+            lumaexr::pxr24_decode_block(payload, (size_t)dsz, layout, (int)W, (int)lines, raw);
+            if (raw.size() != expect)
+                throw LumaException("EXR: PXR24 block has the wrong size");
         } else {
             tmp.resize(expect);
             uLongf got = (uLongf)expect;
@@ -377,6 +394,8 @@ bool ExrInterface::writeFrame(const char *outputFile, LumaFrame &frame, Compress
 {
     if (frame.buffer == NULL)
         throw LumaException("Frame does not contain any data");
+    if (comp != NO_COMPRESSION && comp != RLE_COMPRESSION && comp != ZIPS_COMPRESSION && comp != ZIP_COMPRESSION)
+        throw LumaException("EXR: writeFrame produces NONE, RLE, ZIPS or ZIP files");
     const unsigned int W = frame.width, H = frame.height;
     Bytes out;
     auto put = [&](const void *p, size_t n) { out.insert(out.end(), (const unsigned char *)p, (const unsigned char *)p + n); };

@@ -21,12 +21,20 @@ int main(int argc, char **argv)
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
     const int iters = argc > 2 ? atoi(argv[2]) : 300;
     int decoded = 0, rejected = 0;
-    for (int comp = 0; comp <= 3; comp++) {
-        LumaFrame f(37, 21, 3);
-        for (size_t i = 0; i < f.pixelCount(); i++)
-            f.buffer[i] = (float)((i * 2654435761u) % 100000u) / 7.0f;
-        const std::string good = dir + "/good.exr", bad = dir + "/bad.exr";
-        ExrInterface::writeFrame(good.c_str(), f, (ExrInterface::Compression)comp, comp == 1);
+    // seeds: one file per compression the writer produces, plus any files named on the command line (the Python tests
+    // pass PIZ and PXR24 files, which only the reader knows)
+    const int nseeds = 4 + (argc > 3 ? argc - 3 : 0);
+    for (int comp = 0; comp < nseeds; comp++) {
+        const std::string bad = dir + "/bad.exr";
+        std::string good = dir + "/good.exr";
+        if (comp <= 3) {
+            LumaFrame f(37, 21, 3);
+            for (size_t i = 0; i < f.pixelCount(); i++)
+                f.buffer[i] = (float)((i * 2654435761u) % 100000u) / 7.0f;
+            ExrInterface::writeFrame(good.c_str(), f, (ExrInterface::Compression)comp, comp == 1);
+        } else {
+            good = argv[3 + comp - 4];
+        }
         std::vector<unsigned char> data;
         {
             FILE *fp = fopen(good.c_str(), "rb");
