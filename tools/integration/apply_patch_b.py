@@ -3,9 +3,9 @@
 
 INTEGRATION.md, way B ("keep the reference's classes, replace only the two hot loops"), as an executable recipe: copies
 the reference's include/luma/luma_{encoder,decoder}.h and src/luma_{encoder,decoder}.cpp into <out_dir> and makes the
-five edits a maintainer would make -- an `#include "lumahip.h"` + a `lumahip_ctx *m_hip` member per class, the bodies of
-LumaEncoder::encode / LumaDecoder::decode replaced by one C-ABI call each, and lumahip_create / lumahip_set_quantizer
-after each class's m_quant.setQuantizer(...).  The edits are located by the identifiers they attach to, so this file
+five edits a maintainer would make -- an `#include "lumahip.h"` + a `lumahip_ctx *m_hip` member per class, the two
+statements of LumaEncoder::encode / LumaDecoder::decode that run the hot loops replaced by one C-ABI call each, and
+lumahip_create / lumahip_set_quantizer after each class's m_quant.setQuantizer(...).  The edits are located by the identifiers they attach to, so this file
 contains none of the reference's text.  tests/test_host_side.py compiles the patched sources (build container only)."""
 import os
 import re
@@ -19,53 +19,29 @@ def sub1(text, pattern, repl, what, flags=re.S):
     return new
 
 
-def replace_inline_body(text, signature_regex, new_body, what):
-    """replace the {...} body that follows the first match of signature_regex (brace matching)"""
-    m = re.search(signature_regex, text)
-    if not m:
-        raise SystemExit("anchor not found: " + what)
-    i = text.index("{", m.end())
-    depth, j = 0, i
-    while True:
-        depth += {"{": 1, "}": -1}.get(text[j], 0)
-        j += 1
-        if depth == 0:
-            break
-    return text[:i] + new_body + text[j:]
-
-
-ENC_BODY = """{
-        // one fused HIP kernel: transformColorSpace(frame, true, preScaling) + setChannels(frame)
-        float avg = 0.0f;
-        unsigned char *planes[3] = {m_rawFrame.planes[0], m_rawFrame.planes[1], m_rawFrame.planes[2]};
-        int rc = lumahip_encode_frame_host(m_hip, frame->buffer, frame->width, frame->height, m_params.preScaling,
-                                           (int)m_params.profile, planes, m_rawFrame.stride, &avg,
-                                           frame->buffer /* the reference transforms the caller's frame in place */);
-        if (rc != LUMAHIP_OK)
-            throw LumaException(lumahip_last_error(m_hip));
-        if (avg <= 1.0f)
-            fprintf(stderr, "\\n\\tWarning! Mean luminance is %f cd/m2. Is input calibrated to physical units? \\n", avg);
-        return run();   // unchanged: vpx_codec_encode + MkvInterface::addFrame
-    }"""
-
-DEC_BODY = """{
-        if (!run())
-            return NULL;
-        if (!m_frame.width)
+ENC_CALL = """// one fused HIP kernel replaces transformColorSpace(frame, true, preScaling) + setChannels(frame)
         {
-            m_frame.width = m_vpxFrame->d_w;
-            m_frame.height = m_vpxFrame->d_h;
-            m_frame.channels = 3;
-            m_frame.init();
+            float avg = 0.0f;
+            unsigned char *planes[3] = {m_rawFrame.planes[0], m_rawFrame.planes[1], m_rawFrame.planes[2]};
+            int rc = lumahip_encode_frame_host(m_hip, frame->buffer, frame->width, frame->height, m_params.preScaling,
+                                               (int)m_params.profile, planes, m_rawFrame.stride, &avg,
+                                               frame->buffer /* the reference transforms the caller's frame in place */);
+            if (rc != LUMAHIP_OK)
+                throw LumaException(lumahip_last_error(m_hip));
+            if (avg <= 1.0f)
+                fprintf(stderr, "\\n\\tWarning! Mean luminance is %f cd/m2. Is input calibrated to physical units? \\n", avg);
         }
-        // one fused HIP kernel: getVpxChannels() + transformColorSpace(&m_frame, false, preScaling)
-        const unsigned char *planes[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
-        int rc = lumahip_decode_frame_host(m_hip, planes, m_params.stride, m_vpxFrame->d_w, m_vpxFrame->d_h,
-                                           m_params.profile, m_params.preScaling, m_frame.buffer);
-        if (rc != LUMAHIP_OK)
-            throw LumaException(lumahip_last_error(m_hip));
-        return &m_frame;
-    }"""
+"""
+
+DEC_CALL = """// one fused HIP kernel replaces getVpxChannels() + transformColorSpace(&m_frame, false, preScaling)
+        {
+            const unsigned char *planes[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
+            int rc = lumahip_decode_frame_host(m_hip, planes, m_params.stride, m_vpxFrame->d_w, m_vpxFrame->d_h,
+                                               m_params.profile, m_params.preScaling, m_frame.buffer);
+            if (rc != LUMAHIP_OK)
+                throw LumaException(lumahip_last_error(m_hip));
+        }
+"""
 
 SETQ = """
     // MI355X hot path: hand the FINAL table to the device (include/lumahip.h)
@@ -85,7 +61,9 @@ def main():
 
     h = rd("include/luma/luma_encoder.h")
     h = sub1(h, r'(#include "vp8cx\.h"\n)', r'\1#include "lumahip.h"\n#include "luma_exception.h"\n#include <cstdio>\n', "encoder includes")
-    h = replace_inline_body(h, r"bool\s+encode\s*\(\s*LumaFrame\s*\*\s*frame\s*\)\s*(?=\{)", ENC_BODY, "LumaEncoder::encode body")
+    # inside the inline encode(): drop the colour-transform statement, turn the setChannels statement into the C-ABI call
+    h = sub1(h, r"[ \t]*m_quant\.transformColorSpace\(\s*frame\s*,\s*true[^;]*;\n", "", "encode: transformColorSpace statement")
+    h = sub1(h, r"[ \t]*setChannels\(\s*frame\s*\)\s*;\n", lambda m: "        " + ENC_CALL, "encode: setChannels statement")
     h = sub1(h, r"(LumaEncoderParams\s+m_params;\n)", r"\1    lumahip_ctx *m_hip = NULL;\n", "encoder member")
     open(os.path.join(out, "luma_encoder.h"), "w").write(h)
 
@@ -95,7 +73,9 @@ def main():
 
     h = rd("include/luma/luma_decoder.h")
     h = sub1(h, r'(#include "vp8dx\.h"\n)', r'\1#include "lumahip.h"\n#include "luma_exception.h"\n', "decoder includes")
-    h = replace_inline_body(h, r"LumaFrame\s*\*\s*decode\s*\(\s*\)\s*(?=\{)", DEC_BODY, "LumaDecoder::decode body")
+    # inside the inline decode(): turn the getVpxChannels statement into the C-ABI call, drop the inverse colour transform
+    h = sub1(h, r"[ \t]*getVpxChannels\(\s*\)\s*;\n", lambda m: "        " + DEC_CALL, "decode: getVpxChannels statement")
+    h = sub1(h, r"[ \t]*m_quant\.transformColorSpace\(\s*&m_frame\s*,\s*false[^;]*;\n", "", "decode: transformColorSpace statement")
     h = sub1(h, r"(LumaDecoderParams\s+m_params;\n)", r"\1    lumahip_ctx *m_hip = NULL;\n", "decoder member")
     open(os.path.join(out, "luma_decoder.h"), "w").write(h)
 
