@@ -205,3 +205,47 @@ def test_integration_examples_compile_against_the_reference(tmp_path):
         # the patched headers shadow the reference's; everything else comes from the reference tree
         subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I" + str(out), "-I" + os.path.join(ref, "include")] + inc + [str(out / f)], check=True)
         assert "lumahip_" in (out / f).read_text() or "lumahip_" in (out / f.replace(".cpp", ".h")).read_text()
+
+
+def test_lumaenc_option_handling_equals_the_reference_parser(tmp_path):
+    """tools/lumaenc's option handling (tools/luma_cli.h) against the reference's own ArgParser (src/arg_parser.cpp compiled
+    unmodified behind lumaenc's option table: oracle/_ref/ref_argparser_tool, build container only) on the same command
+    lines: same accept / reject decision, same message, same parsed values -- atoi / atof conversions, range and
+    value-set checks, repeated options, missing values, help."""
+    tool = os.path.join(ROOT, "oracle", "_ref", "ref_argparser_tool")
+    if not os.path.exists(tool):
+        if not os.path.isdir("/root/reference/src"):
+            pytest.skip("needs /root/reference")
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_args"], check=True)
+    enc = os.path.join(ROOT, "lumahdrv_amd", "bin", "lumaenc")
+    rng = np.random.default_rng(12)
+    lines = [
+        ["-o", "a.lhs"], ["--output", "a.lhs", "-i", "__test__", "-f", "1:2:9"], ["-o", "a.lhs", "-p", "0", "-q", "63", "-sc", "2.5e3"],
+        ["-o", "a.lhs", "-pb", "16", "-cb", "0", "-ptf", "HDRVDP", "-cs", "XYZ", "-ma", "100", "-mi", "99.99"],
+        ["-o", "a.lhs", "-b", "9999", "-k", "9999", "-eb", "8", "-l", "-v", "-fps", "59.94"],
+        ["-o", "a.lhs", "-p", "3", "-p", "1"], ["-o", "a.lhs", "-p", "-1"], ["-o", "a.lhs", "-p", "abc"], ["-o", "a.lhs", "-p", "2.9"],
+        ["-o", "a.lhs", "-sc", "-1"], ["-o", "a.lhs", "-sc", "1e21"], ["-o", "a.lhs", "-ma", "99.9"], ["-o", "a.lhs", "-mi", "0"],
+        ["-o", "a.lhs", "-eb", "11"], ["-o", "a.lhs", "-ptf", "PQ "], ["-o", "a.lhs", "-cs", "luv"], ["-o", "a.lhs", "-q"],
+        ["-o", "a.lhs", "--lossless", "--verbose", "--bogus"], ["-i", "x"], [], ["-o", "a.lhs", "-h"], ["--help"], ["-o", "a.lhs", "-l", "1"],
+    ]
+    names = [("-p", "--profile"), ("-q", "--quantizer-scaling"), ("-pb", "--ptf-bitdepth"), ("-cb", "--color-bitdepth"), ("-b", "--bitrate"),
+             ("-k", "--keyframe-interval"), ("-eb", "--encoding-bitdepth"), ("-sc", "--pre-scaling"), ("-ma", "--max-luminance"),
+             ("-mi", "--min-luminance"), ("-fps", "--framerate")]
+    for _ in range(150):                                     # random numeric options with values around their limits
+        args = ["-o", "r.lhs"]
+        for _ in range(int(rng.integers(1, 5))):
+            short, long_ = names[int(rng.integers(0, len(names)))]
+            v = rng.choice(["0", "1", "3", "4", "8", "9", "10", "12", "16", "17", "63", "64", "99", "100", "9999", "10000", "1e-10", "1e-11",
+                            "99.99", "100.5", "1e5", "100001", "0.5", "-3", "x"])
+            args += [short if rng.random() < 0.5 else long_, str(v)]
+        lines.append(args)
+    for args in lines:
+        ref = subprocess.run([tool] + args, capture_output=True, text=True, timeout=30).stdout.strip()
+        r = subprocess.run([enc] + args, capture_output=True, text=True, timeout=30, env=dict(os.environ, LUMAENC_PRINT_ARGS="1"))
+        if ref.startswith("OK "):
+            assert r.returncode == 0 and r.stdout.strip() == ref, (args, ref, r.stdout, r.stderr)
+        elif ref == "HELP":
+            assert r.returncode == 1 and "Available options:" in r.stderr, (args, r.stderr)
+        else:
+            assert ref.startswith("ERR ")
+            assert r.returncode == 1 and ("lumaenc input error: " + ref[4:]) in r.stderr, (args, ref, r.stderr)

@@ -8,6 +8,7 @@
 // --encoding-bitdepth, --lossless) are parsed, range-checked and stored in LumaEncoderParams exactly as the reference
 // does; nothing in the hot path reads them.  PFS streams are not supported (the reference needs pfstools for them, too).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -18,14 +19,14 @@
 namespace {
 
 struct Job {
-    std::string frames, output;
+    std::string frames, output, range, ptfText, csText;  // the last three as given, for LUMAENC_PRINT_ARGS
     unsigned int first = 1, last = 9999, step = 1;  // lumaenc.cpp:51-52
     bool verbose = false;
 };
 
 bool configure(int argc, char **argv, LumaEncoderParams &p, Job &job)
 {
-    std::string range, ptf, cs;
+    std::string &range = job.range, &ptf = job.ptfText, &cs = job.csText;
     lumacli::Options opt(
         "lumaenc -- Compress a sequence of high dyncamic range (HDR) frames in to a Luma HDRv plane stream (.lhs) on an MI355X\n\n"
         "Usage: lumaenc --input <hdr_frames> \\\n"
@@ -98,6 +99,16 @@ int main(int argc, char *argv[])
         if (!configure(argc, argv, params, job))
             return 1;
         encoder.setParams(params);
+        if (std::getenv("LUMAENC_PRINT_ARGS")) {  // tests: what the command line was understood as (same line format as
+                                                  // oracle/ref_argparser_harness.cpp prints for the reference's parser)
+            std::printf("OK input=%s output=%s frames=%s fps=%.9g profile=%u q=%u sc=%.9g pb=%u cb=%u ptf=%s cs=%s ma=%.9g mi=%.9g "
+                        "b=%u k=%u eb=%u l=%d v=%d\n",
+                        job.frames.c_str(), job.output.c_str(), job.range.c_str(), params.fps, params.profile, params.quantizerScale,
+                        params.preScaling, params.ptfBitDepth, params.colorBitDepth, job.ptfText.c_str(), job.csText.c_str(),
+                        params.maxLum, params.minLum, params.bitrate, params.keyframeInterval, params.bitDepth, (int)params.lossLess,
+                        (int)job.verbose);
+            return 0;
+        }
         int done = 0;
         for (unsigned int f = job.first; f <= job.last; f += job.step) {
             LumaFrame frame;
