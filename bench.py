@@ -247,6 +247,8 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             probe_ms = float(np.median([ctx.probe_encode_traffic(ptrs(i % nbatch)[0], n3, B, w, h, ptrs(i % nbatch)[2], st, psz)
                                         for i in range(max(5, min(25, nbatch)))]))
         tr = load_profile(os.path.join(args.profile_dir, "traffic_latest.json"), name, px_step, sha)
+        if tr and tr.get("pixels_per_launch") != px_step:
+            tr = None                                     # captured for a different launch size: not this launch's bytes
         common = {"kernel": kname, "kernel_ms": round(avg_ms, 4), "kernel_ms_isolated_launch": round(float(np.median(iso)), 4),
                   "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                   "traffic_source": ("rocprofv3 PMC passes of tools/profile_round.sh (2 x FETCH_SIZE + WRITE_SIZE), captured "
