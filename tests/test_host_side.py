@@ -249,3 +249,26 @@ def test_lumaenc_option_handling_equals_the_reference_parser(tmp_path):
         else:
             assert ref.startswith("ERR ")
             assert r.returncode == 1 and ("lumaenc input error: " + ref[4:]) in r.stderr, (args, ref, r.stderr)
+
+
+def test_bench_reports_counter_figures_only_for_matching_kernel_sources(tmp_path):
+    """bench.py's roofline.traffic / VALU mix come from committed rocprofv3 captures; they must be dropped (null) when the
+    capture was made from other kernel sources or for another launch size -- never reported stale."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from lumahdrv_amd import capi
+    sha = capi.kernel_source_sha()
+    p = tmp_path / "t.json"
+    json.dump({"pq11_luv": {"workload": "pq11_luv", "kernel_source_sha": sha, "pixels_per_launch": 100.0, "hbm_bytes_per_launch": 1500.0}}, open(p, "w"))
+    assert b.load_profile(str(p), "pq11_luv", 100.0, sha)["hbm_bytes_per_launch"] == 1500.0
+    assert b.load_profile(str(p), "pq11_luv", 100.0, "0" * 12) is None          # other sources
+    assert b.load_profile(str(p), "log12_luv", 100.0, sha) is None              # other workload
+    assert b.load_profile(str(tmp_path / "missing.json"), "pq11_luv", 100.0, sha) is None
+    # the committed captures belong to the committed sources
+    for f in ("traffic_latest.json", "valu_mix_latest.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", f)))
+        assert set(d) == {"pq11_luv", "pq10_ycbcr", "log12_luv"}
+        assert all(v["kernel_source_sha"] == sha for v in d.values()), "re-run tools/profile_round.sh + summarize_profile.py after kernel changes"
