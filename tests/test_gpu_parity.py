@@ -693,3 +693,41 @@ print("LIB", capi.library_path())
             assert same_bits(a, b_), k
         else:
             assert np.array_equal(a, b_), k
+
+
+def test_random_monotone_tables_through_the_encode_kernel(L, oracle_mod):
+    """Arbitrary attachment-434 style tables (random non-decreasing, 10- and 12-bit, log-uniform over 60 decades / linear /
+    with a duplicate) through k_encode<CS_RGB, 4:4:4> with whatever search the library picks (records in LDS or global
+    memory, or the literal bisection when the builder refuses the table), on every table entry's neighbourhood and the
+    midpoints' rounding-tie zone: planes bit-exact against the oracle's literal search."""
+    o = oracle_mod
+    rng = np.random.default_rng(77)
+    modes = set()
+    for trial in range(12):
+        bits = 10 if trial % 2 else 12
+        n = 1 << bits
+        if trial % 3 == 0:
+            m = np.sort(np.exp(rng.uniform(np.log(1e-30), np.log(1e30), n))).astype(np.float32)
+        elif trial % 3 == 1:
+            m = np.sort(rng.uniform(0, 1e4, n)).astype(np.float32)
+        else:
+            m = np.sort(np.exp(rng.uniform(np.log(1e-3), np.log(1e5), n))).astype(np.float32)
+            m[n // 2 + 1] = m[n // 2]
+            if trial == 8:
+                m[7:10] = m[7]                      # a triple: the record builder refuses, literal kernels take over
+        q = L.LumaQuantizer()
+        q.setQuantizer(L.PTF_PQ, bits, L.CS_RGB, 8, 1e4, 0.005, mapping_override=m)
+        modes.add(q.ctx.quantizer_info()["mode"])
+        orc = o.Oracle(o.PTF_PQ, bits, o.CS_RGB, 8, 1e4, 0.005)
+        orc.overwrite_mapping(m)
+        mids = ((m[:-1].astype(np.float64) + m[1:]) / 2).astype(np.float32)
+        v = np.concatenate([m, np.nextafter(m, np.float32(np.inf)), np.nextafter(m, np.float32(-np.inf)), mids,
+                            np.nextafter(mids, np.float32(np.inf)), np.nextafter(mids, np.float32(-np.inf)),
+                            np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38], dtype=np.float32)])
+        v = np.concatenate([v, np.ones((-v.size) % 8, dtype=np.float32)])
+        frame = np.stack([v.reshape(2, -1), v[::-1].reshape(2, -1), np.roll(v, 3).reshape(2, -1)]).copy()
+        planes, st, _ = q.ctx.encode_frame(frame, 1.0, 3)
+        exp, _, _ = orc.encode(frame.copy(), 1.0, 3)
+        for p in range(3):
+            assert np.array_equal(planes[p], exp[p]), (trial, p)
+    assert 0 in modes and (3 in modes or 4 in modes)

@@ -272,3 +272,49 @@ def test_bench_reports_counter_figures_only_for_matching_kernel_sources(tmp_path
         d = json.load(open(os.path.join(ROOT, "profiles", f)))
         assert set(d) == {"pq11_luv", "pq10_ycbcr", "log12_luv"}
         assert all(v["kernel_source_sha"] == sha for v in d.values()), "re-run tools/profile_round.sh + summarize_profile.py after kernel changes"
+
+
+def test_threshold_records_on_random_monotone_tables(L, oracle_mod):
+    """A decoder may be handed ANY attachment-434 table.  Random non-decreasing tables (log-uniform over 60 decades,
+    linear, with zeros, denormals, duplicates, huge last entries; 2 ... 4096 entries): wherever the record builder
+    accepts a table, its records must equal the oracle's literal search on the table's neighbourhoods and on a random
+    sample; tables it refuses (codes jumping by two at one float) simply take the literal kernels."""
+    from lumahdrv_amd import capi
+    o = oracle_mod
+    rng = np.random.default_rng(2024)
+    accepted = refused = 0
+    for trial in range(60):
+        bits = int(rng.choice([1, 2, 3, 6, 10, 12]))
+        n = 1 << bits
+        kind = trial % 4
+        if kind == 0:
+            m = np.sort(np.exp(rng.uniform(np.log(1e-30), np.log(1e30), n))).astype(np.float32)
+        elif kind == 1:
+            m = np.sort(rng.uniform(0, 1e4, n)).astype(np.float32)
+        elif kind == 2:
+            m = np.sort(np.exp(rng.uniform(np.log(1e-44), np.log(1e-30), n))).astype(np.float32)      # denormals and tiny values
+            m[0] = 0.0
+        else:
+            m = np.sort(np.exp(rng.uniform(np.log(1e-3), np.log(1e5), n))).astype(np.float32)
+            k = int(rng.integers(0, n - 1))
+            m[k + 1] = m[k]                                                                            # one duplicate
+        ix = capi.thresh_index(m)
+        if not ix["ok"]:
+            refused += 1
+            continue
+        accepted += 1
+        orc = o.Oracle(o.PTF_PQ, bits, o.CS_RGB, 8, 1e4, 0.005)
+        orc.overwrite_mapping(m)
+        mids = ((m[:-1].astype(np.float64) + m[1:]) / 2).astype(np.float32)
+        v = np.concatenate([m, np.nextafter(m, np.float32(np.inf)), np.nextafter(m, np.float32(-np.inf)), mids,
+                            np.nextafter(mids, np.float32(np.inf)), np.nextafter(mids, np.float32(-np.inf)),
+                            np.exp(rng.uniform(np.log(1e-45), np.log(3e38), 20000)).astype(np.float32),
+                            np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38], dtype=np.float32)])
+        v = np.concatenate([v, np.ones((-v.size) % 2, dtype=np.float32)])
+        got = capi.thresh_lookup(ix, v)
+        frame = np.stack([v.reshape(2, -1)] * 3).copy()
+        planes, _, _ = orc.encode(frame, 1.0, 3 if bits > 8 else 1)
+        w = frame.shape[2]
+        exp = (planes[0].view("<u2")[:, :w] if bits > 8 else planes[0][:, :w]).reshape(-1).astype(np.int64)
+        assert np.array_equal(got & (0xFFFF if bits > 8 else 0xFF), exp), (trial, bits, kind)
+    assert accepted >= 40 and accepted + refused == 60
