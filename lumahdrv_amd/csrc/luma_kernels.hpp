@@ -257,9 +257,9 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
 // LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global).
 //
-// Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued while the current
-// unit is still being searched / packed / stored (without this the kernel sat at ~45 % SQ_WAIT_ANY,
-// profiles/r01_early_pmc_summary.txt).
+// Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued at the end of the current
+// unit's iteration, one full iteration before they are needed (without this the kernel sat at ~45 % SQ_WAIT_ANY,
+// profiles/r01_early_pmc_summary.txt); see the loop in k_encode for the order of loads and stores.
 
 template <int VW>
 struct EncUnit {
@@ -451,9 +451,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     st.mn = __builtin_inff();
     st.mx = -__builtin_inff();
 
-    // Software pipeline: transform the current unit, THEN issue the next unit's loads (the current inputs are
-    // dead by then, so both units share one set of registers), then search / pack / store the current unit
-    // while the next unit's 6 KiB per wave are in flight.
+    // Per unit: transform, search / pack / store, THEN issue the next unit's loads (the current inputs are dead by then,
+    // so both units share one set of registers); the other waves of the SIMD cover the load latency.  Issuing the loads
+    // before the stores (round 1) measured 1.0-1.3 % slower HBM-fed, same-box, 5 of 5 interleaved rounds: with the
+    // stores first the write bursts of a wave are not queued behind its own 6 KiB of reads.
     EncUnit<VW> u;
     enc_load<VW>(u, a, blockIdx.x, tx, ty, NW, cs);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
@@ -469,7 +470,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         float c0[2 * VW], c1[2 * VW], c2[2 * VW];
         if (valid)
             enc_transform<CS, VW>(u, a, k, c0, c1, c2, st);
-        enc_load<VW>(u, a, t + G, tx, ty, NW, cs);
         if (valid) {
             if constexpr (LM == 3)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
@@ -480,6 +480,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
             else
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_rec);
         }
+        enc_load<VW>(u, a, t + G, tx, ty, NW, cs);
     }
     if (a.stats)
         stats_flush(st, a.stats, tx);
@@ -722,13 +723,15 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     DecUnit<SUB, VW> cur, nxt;
     dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
-        dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         if (cur.valid) {
             if constexpr (GL)
                 dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv, cs);
             else
                 dec_process<CS, SUB, VW, DISP, UVTAB>(cur, a, k, s_lut, s_uv, cs);
         }
+        // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
+        // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)
+        dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         cur = nxt;
     }
 }
