@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_encode_traffic_probe(const EncArgs a)
 
 // ---- DECODE ---------------------------------------------------------------------------------------
 // GL: LUT read from global memory (bitdepth > 12) instead of LDS.  Same software pipeline as encode: the
-// sample loads of the next unit are issued before the current unit is dequantized and transformed.
+// sample loads of the next unit are issued one iteration ahead, after the current unit's stores.
 template <bool SUB, int VW>
 struct DecUnit {
     int y[2][VW];
