@@ -30,6 +30,9 @@ using namespace lh;
 #ifndef EXP_LM
 #define EXP_LM 3
 #endif
+#ifndef EXP_CS
+#define EXP_CS 0  // 0 = CS_LUV (PQ-11, the headline), 2 = CS_YCBCR (the HDR10 recipe: PQ-10, 1000 cd/m2, preScaling 20)
+#endif
 
 static bool geom(FrameGeom &g, int w, int h, int vw, int nw, int nframes)
 {
@@ -43,10 +46,11 @@ int main(int argc, char **argv)
 {
     const int threads = argc > 1 ? atoi(argv[1]) : 256;
     const int percu = argc > 2 ? atoi(argv[2]) : 2048 / threads;
-    const int ptf = argc > 3 ? atoi(argv[3]) : 1, bits = argc > 4 ? atoi(argv[4]) : 11;
+    const int ptf = argc > 3 ? atoi(argv[3]) : 1, bits = argc > 4 ? atoi(argv[4]) : (EXP_CS == 2 ? 10 : 11);
+    const float maxLum = EXP_CS == 2 ? 1000.0f : 1e4f;
     const size_t n = (size_t)1 << bits;
     std::vector<float> lut(n);
-    if (lumahip_build_lut(ptf, bits, 1e4f, 0.005f, lut.data(), n)) return 2;
+    if (lumahip_build_lut(ptf, bits, maxLum, 0.005f, lut.data(), n)) return 2;
     ThreshIndex ix = build_thresh_index(lut.data(), (int)n, 1 << 19);
     if (!ix.ok) return 3;
     QuantDev q{};
@@ -61,8 +65,8 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
     q.lut = d_lut; q.rec = d_rec; q.lut_len = (int)n; q.pad = (int)(padded.size() - n);
     q.maxVal = (int)n - 1; q.mode = LUT_THRESH_LDS; q.shift = ix.shift; q.kmin = ix.kmin; q.nbuckets = ix.nbuckets;
-    q.maxC = 255.0f; q.cs = CS_LUV; q.Lmax = 1e4f;
-    const size_t lds = EXP_LM == 3 ? (((size_t)ix.nbuckets * 4 + 15) & ~(size_t)15) : 0;
+    q.maxC = EXP_CS == 2 ? 1023.0f : 255.0f; q.cs = EXP_CS; q.Lmax = maxLum;
+    const size_t lds = (EXP_LM == 3 ? (((size_t)ix.nbuckets * 4 + 15) & ~(size_t)15) : 0) + (EXP_CS == 2 ? sizeof(PowfTables) : 0);
 
     const int W = 3840, H = 2160, B = 20;
     const size_t n3 = (size_t)3 * W * H;
@@ -78,7 +82,7 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) == hipSuccess) ncu = prop.multiProcessorCount;
 
-    auto kern = k_encode<CS_LUV, true, 4, EXP_LM>;
+    auto kern = k_encode<EXP_CS, true, 4, EXP_LM>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     struct Case { const char *name; int w, h, nf; size_t fs; bool alias; };
     const Case cases[] = {{"L2-fed  512x512 ", 512, 512, B * W * H / (512 * 512), 0, true},
@@ -88,7 +92,7 @@ int main(int argc, char **argv)
         EncArgs a{};
         a.q = q;
         geom(a.g, cs.w, cs.h, 4, threads / 64, cs.nf);
-        a.frame_stride = cs.fs; a.sc = 1.0f; a.bps = 2; a.aligned = 1; a.stats = nullptr;
+        a.frame_stride = cs.fs; a.sc = EXP_CS == 2 ? 20.0f : 1.0f; a.bps = 2; a.aligned = 1; a.stats = nullptr;
         const int cst[3] = {cs.w * 2, cs.w, cs.w};
         long grid = std::min<long>((long)ncu * percu, a.g.totalTiles);
         std::vector<float> ms;
