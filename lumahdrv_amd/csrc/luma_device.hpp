@@ -40,6 +40,10 @@ LH_DEV float clamp_xyz(float v)
     return __builtin_elementwise_maximum(__builtin_elementwise_minimum(v, 100000000.0f), 0.0001f);
 }
 
+// std::max(v, 1e-10f), src/luma_quantizer.cpp:331-333: (v < 1e-10f) ? 1e-10f : v -- a NaN v passes through, anything
+// else (-0, negatives, -inf) becomes 1e-10f: IEEE-754-2019 maximum, one v_maximum3_f32 instead of compare + select.
+LH_DEV float floor_1e10(float v) { return __builtin_elementwise_maximum(v, 1e-10f); }
+
 // ---------------------------------------------------------------------------------------------------
 // Division.
 //
@@ -122,14 +126,14 @@ LH_DEV float div_255_pos(float a)
 struct XformConst {
     float sc;               // preScaling
     float Lmax;             // PQ peak for the YCbCr path
-    const PowfTables *pw;   // powf tables (LDS copy), YCbCr only
+    const PowfTablesWide *pw;  // powf tables (LDS copy), YCbCr only
     // refined reciprocals (rcp_nr) of the YCbCr path's constant divisors, computed once per thread instead of once
     // per division: div_nr_r(a, b, rcp_nr(b)) is div_nr(a, b) by definition
     float rLmax, r18814, r14746, r224, r0678;
 };
 
 template <int CS>
-LH_DEV XformConst make_xform_const(float sc, float Lmax, const PowfTables *pw)
+LH_DEV XformConst make_xform_const(float sc, float Lmax, const PowfTablesWide *pw)
 {
     XformConst k;
     k.sc = sc;
@@ -171,9 +175,13 @@ LH_DEV float pq_decode(float val, const XformConst &k)
 // Lmax in [1e-6, 1e9] is checked by the caller.
 struct SlowAcc {
     uint32_t umax = 0;
+    uint32_t umin = 0xffffffffu;  // running unsigned min of (bits(x) - 1) over arguments that must be +0 or >= pw_range_low
     bool flag = false;
 };
-LH_DEV bool slow_any(const SlowAcc &a) { return a.flag || a.umax >= 0x7f000000u; }
+LH_DEV bool slow_any(const SlowAcc &a, const XformConst &k)
+{
+    return a.flag || a.umax >= pw_range_limit(*k.pw) || a.umin < pw_range_low(*k.pw) - 1u;
+}
 
 // pq_encode_r<ANYVAL>: with ANYVAL (decode side: val is a table value, possibly 0, tiny, negative or NaN) the first
 // power tests its argument itself (ZERO, CHECK_X).  Without (encode side: val in [1e-10, FLT_MAX], or NaN / +inf) the
@@ -190,7 +198,7 @@ LH_DEV float pq_encode_r(float val, const XformConst &k, SlowAcc &acc)
     if constexpr (ANYVAL) {
         Lp = powf_regular<true, true, false>(x1, n, *k.pw, acc.flag);
     } else {
-        acc.umax = max(acc.umax, __float_as_uint(x1) - 0x00800000u);
+        acc.umax = max(acc.umax, pw_range_key(*k.pw, __float_as_uint(x1)));
         Lp = powf_regular<false, false, false>(x1, n, *k.pw, acc.flag);
     }
     return powf_regular<false, false, false>(div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, acc.flag);
@@ -208,7 +216,9 @@ LH_DEV float pq_decode_r(float val, const XformConst &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float Vp = powf_regular<!BOUNDED, false, false>(val, 1.0f / m, *k.pw, acc.flag);
-    return k.Lmax * powf_regular<!BOUNDED, false, !BOUNDED>(div_nr(std_max(0.0f, Vp - c1), c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
+    // std::max(0.0f, Vp - c1): with BOUNDED the difference is positive and the max is the identity
+    const float num = BOUNDED ? Vp - c1 : std_max(0.0f, Vp - c1);
+    return k.Lmax * powf_regular<!BOUNDED, false, !BOUNDED>(div_nr(num, c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
 }
 
 template <int CS>
@@ -274,9 +284,9 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
 {
     float R, G, B;
     if constexpr (REGULAR) {
-        R = pq_encode_r<false>(std_max(r, 1e-10f), k, slow);
-        G = pq_encode_r<false>(std_max(g, 1e-10f), k, slow);
-        B = pq_encode_r<false>(std_max(b, 1e-10f), k, slow);
+        R = pq_encode_r<false>(floor_1e10(r), k, slow);
+        G = pq_encode_r<false>(floor_1e10(g), k, slow);
+        B = pq_encode_r<false>(floor_1e10(b), k, slow);
     } else {
         R = pq_encode(std_max(r, 1e-10f), k);
         G = pq_encode(std_max(g, 1e-10f), k);
@@ -308,7 +318,7 @@ LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&
 #pragma unroll
     for (int i = 0; i < N; i++)
         ycbcr_fwd<true>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
-    if (__builtin_expect(slow_any(slow), 0)) {
+    if (__builtin_expect(slow_any(slow, k), 0)) {
         for (int i = 0; i < N; i++)  // not unrolled: cold code
             ycbcr_fwd<false>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
     }
@@ -354,10 +364,17 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
         red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
         green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
     }
+    // (the compiler turns these compare + select pairs into v_min_f32 / v_max_f32 itself: a NaN becomes 1, -0 becomes +0)
     red = std_max(0.0f, std_min(1.0f, red));
     green = std_max(0.0f, std_min(1.0f, green));
     blue = std_max(0.0f, std_min(1.0f, blue));
     if constexpr (REGULAR) {
+        // The powers below take arguments that are +0 or at least 2^-64 (the wide log2 table of pow_glibc.hpp).  red and
+        // blue: y is 0 or |y| >= 2^-20/219 (255*P - 16 is a multiple of 2^-20 where it can cancel), the chroma term is 0 or
+        // >= 2^-17*1.47/224 likewise, so their float sum is 0 or a multiple of 2^-51.  green is a difference of
+        // differences and has no such bound that is short to prove: it joins the running minimum (one subtract and one
+        // unsigned min per pixel), and a pixel below the bound sends the unit to the complete functions.
+        slow.umin = min(slow.umin, __float_as_uint(green) - 1u);
         r = pq_decode_r<false>(red, k, slow);
         g = pq_decode_r<false>(green, k, slow);
         b = pq_decode_r<false>(blue, k, slow);
@@ -380,7 +397,7 @@ LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float 
         slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f && c0[i] <= 3.0e38f);
         ycbcr_inv<true>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
     }
-    if (__builtin_expect(slow_any(slow), 0)) {
+    if (__builtin_expect(slow_any(slow, k), 0)) {
         for (int i = 0; i < N; i++)  // not unrolled: cold code
             ycbcr_inv<false>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
     }

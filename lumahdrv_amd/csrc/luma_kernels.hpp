@@ -75,31 +75,38 @@ struct DecArgs {
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
 enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16 };
 
+// fill the LDS copy of the powf tables (pow_glibc.hpp); the caller synchronises
+LH_DEV void stage_powf_tables(PowfTablesWide *t)
+{
+    const double lt[16][2] = LH_POWF_LOG2_TAB;
+    const uint64_t et[32] = LH_POWF_EXP2_TAB;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 16) {
+        t->log2_tab[tid][0] = lt[tid][0];
+        t->log2_tab[tid][1] = lt[tid][1];
+    }
+    if (tid < 32)
+        t->exp2_tab[tid] = et[tid];
+    for (int e = tid; e < 2048; e += nt)
+        pw_wide_entry(e, lt, t->wide[e][0], t->wide[e][1]);
+}
+
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
 LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
 
 // offset of the search table / records behind the powf tables
 template <int WHAT>
-constexpr int lds_table_offset() { return (WHAT & STAGE_POWF) ? (int)sizeof(PowfTables) : 0; }
+constexpr int lds_table_offset() { return (WHAT & STAGE_POWF) ? (int)sizeof(PowfTablesWide) : 0; }
 
 template <int WHAT>
 LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q)
 {
-    static_assert(sizeof(PowfTables) % 16 == 0, "the tables behind the powf tables must stay 16-byte aligned");
+    static_assert(sizeof(PowfTablesWide) % 16 == 0, "the tables behind the powf tables must stay 16-byte aligned");
     static_assert(!((WHAT & STAGE_LUT) && (WHAT & STAGE_REC)), "one search table per kernel");
     const int tid = threadIdx.x, nt = blockDim.x;
     constexpr int off = lds_table_offset<WHAT>();
-    if constexpr (WHAT & STAGE_POWF) {
-        PowfTables *t = reinterpret_cast<PowfTables *>(smem);
-        const double lt[16][2] = LH_POWF_LOG2_TAB;
-        const uint64_t et[32] = LH_POWF_EXP2_TAB;
-        if (tid < 16) {
-            t->log2_tab[tid][0] = lt[tid][0];
-            t->log2_tab[tid][1] = lt[tid][1];
-        }
-        if (tid < 32)
-            t->exp2_tab[tid] = et[tid];
-    }
+    if constexpr (WHAT & STAGE_POWF)
+        stage_powf_tables(reinterpret_cast<PowfTablesWide *>(smem));
     if constexpr (WHAT & STAGE_LUT) {
         // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
         const int n4 = lds_lut_bytes(q) / 16;
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
 
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());        // LM == 0
     const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem + lds_table_offset<WHAT>());  // LM == 3
-    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTables *>(smem));
+    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTablesWide *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
     const float *s_uv = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_lut_bytes(a.q));
-    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTables *>(smem));
+    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTablesWide *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -750,16 +757,10 @@ struct XfArgs {
 template <int CS, bool FWD>
 __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
 {
-    __shared__ PowfTables s_pw;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[CS == CS_YCBCR ? sizeof(PowfTablesWide) : 16];
+    PowfTablesWide &s_pw = *reinterpret_cast<PowfTablesWide *>(s_raw);
     if constexpr (CS == CS_YCBCR) {
-        const double lt[16][2] = LH_POWF_LOG2_TAB;
-        const uint64_t et[32] = LH_POWF_EXP2_TAB;
-        if (threadIdx.x < 16) {
-            s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
-            s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
-        }
-        if (threadIdx.x < 32)
-            s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+        stage_powf_tables(&s_pw);
         __syncthreads();
     }
     const XformConst k = make_xform_const<CS>(a.sc, a.Lmax, &s_pw);
@@ -798,16 +799,10 @@ __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
 template <int CS>
 __global__ __launch_bounds__(256) void k_channel0(const float *src, size_t chan_stride, size_t n, float sc, float Lmax, float *out)
 {
-    __shared__ PowfTables s_pw;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[CS == CS_YCBCR ? sizeof(PowfTablesWide) : 16];
+    PowfTablesWide &s_pw = *reinterpret_cast<PowfTablesWide *>(s_raw);
     if constexpr (CS == CS_YCBCR) {
-        const double lt[16][2] = LH_POWF_LOG2_TAB;
-        const uint64_t et[32] = LH_POWF_EXP2_TAB;
-        if (threadIdx.x < 16) {
-            s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
-            s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
-        }
-        if (threadIdx.x < 32)
-            s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+        stage_powf_tables(&s_pw);
         __syncthreads();
     }
     const XformConst k = make_xform_const<CS>(sc, Lmax, &s_pw);
@@ -925,15 +920,8 @@ __global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
 // ---- powf probe: out[i] = powf_glibc(bits-to-float(first + i), y) (tests: device powf == host libm, exhaustively)
 __global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_bits, size_t n, float y, int regular)
 {
-    __shared__ PowfTables s_pw;
-    const double lt[16][2] = LH_POWF_LOG2_TAB;
-    const uint64_t et[32] = LH_POWF_EXP2_TAB;
-    if (threadIdx.x < 16) {
-        s_pw.log2_tab[threadIdx.x][0] = lt[threadIdx.x][0];
-        s_pw.log2_tab[threadIdx.x][1] = lt[threadIdx.x][1];
-    }
-    if (threadIdx.x < 32)
-        s_pw.exp2_tab[threadIdx.x] = et[threadIdx.x];
+    __shared__ PowfTablesWide s_pw;
+    stage_powf_tables(&s_pw);
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float x = __uint_as_float(first_bits + (uint32_t)i);

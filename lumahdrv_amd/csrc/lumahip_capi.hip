@@ -57,6 +57,14 @@ struct lumahip_ctx {
     float *h_stats = nullptr;  // pinned, 3 floats per frame
     size_t h_stats_cap = 0;
 
+    // Pinned staging for pageable caller memory (see xfer_h2d): two chunks per direction, ping-pong
+    struct Stage {
+        unsigned char *h = nullptr;
+        hipEvent_t ev = nullptr;
+        bool pending = false;  // a DMA that reads / writes this chunk may still be in flight
+    } stage_up[2], stage_dn[2];
+    float *h_small = nullptr;  // pinned scratch for the few-float readbacks
+
     int block_threads = 256;
     bool block_forced = false;
     bool allow_alias = false;  // LUMAHIP_ALLOW_ALIASED_FRAMES=1: measurement tools alias all frames of a batch onto one
@@ -159,6 +167,12 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
         if (sl.d2h) (void)hipEventDestroy(sl.d2h);
     }
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    for (auto *st : {&c->stage_up[0], &c->stage_up[1], &c->stage_dn[0], &c->stage_dn[1]}) {
+        if (st->ev) (void)hipEventSynchronize(st->ev);
+        if (st->h) (void)hipHostFree(st->h);
+        if (st->ev) (void)hipEventDestroy(st->ev);
+    }
+    if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_kern) (void)hipStreamDestroy(c->s_kern);
     if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
@@ -296,7 +310,7 @@ static size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
             b += (((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15;  // u'v' table of the Lu'v' decode kernels
     }
     if (cs_eff == CS_YCBCR)
-        b += sizeof(PowfTables);
+        b += sizeof(PowfTablesWide);
     return b;
 }
 
@@ -774,6 +788,162 @@ extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const f
 
 // ---------------------------------------------------------------------------------------- host entry points
 
+// ---- host <-> device transfers of the _host entry points --------------------------------------------------------
+// Caller memory is pageable unless the caller pinned it (hipHostMalloc, hipHostRegister / lumahip_host_register).
+// Pinned memory is handed to the copy engine directly (asynchronous, the fast path of the batched entry points).
+// Pageable memory is NOT handed to hipMemcpy*Async: the runtime then pins the caller's pages on the fly and caches
+// that pinning, and on this stack (ROCm 7.2, MI355X) the GPU occasionally faulted on such a range when host buffers are
+// allocated and freed at a high rate ("Memory access fault by GPU ... on address <host heap page>", about one run of
+// the GPU test suite in twenty).  Pageable data therefore moves through two context-owned pinned chunks per direction:
+// the CPU copy of chunk k+1 overlaps the DMA of chunk k.
+static constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+
+static bool host_range_is_pinned(const void *p, size_t bytes)
+{
+    if (!p || !bytes)
+        return false;
+    const unsigned char *ends[2] = {(const unsigned char *)p, (const unsigned char *)p + bytes - 1};
+    for (const unsigned char *q : ends) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();  // plain malloc memory: not an error of ours
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost)
+            return false;
+    }
+    return true;
+}
+
+static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
+{
+    if (!st.h) {
+        HIPCHK(c, hipHostMalloc((void **)&st.h, XFER_CHUNK, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    }
+    if (st.pending) {
+        HIPCHK(c, hipEventSynchronize(st.ev));
+        st.pending = false;
+    }
+    return LUMAHIP_OK;
+}
+
+// rows x width bytes, host pitch hp, device pitch dp.  Returns once the copies are queued on `s` (the caller's buffer
+// is no longer needed if it was pageable: it has been copied into the staging chunks).
+static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, size_t hp, size_t width, size_t rows, hipStream_t s)
+{
+    if (!width || !rows)
+        return LUMAHIP_OK;
+    if (host_range_is_pinned(src, (rows - 1) * hp + width)) {
+        if (dp == width && hp == width)
+            HIPCHK(c, hipMemcpyAsync(dst, src, width * rows, hipMemcpyHostToDevice, s));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dst, dp, src, hp, width, rows, hipMemcpyHostToDevice, s));
+        return LUMAHIP_OK;
+    }
+    // staged: the device side is written as whole rows of dp bytes (the padding between rows belongs to the context's
+    // own buffers), so that one chunk is one contiguous DMA
+    const bool flat = (dp == width && hp == width);
+    if (!flat && dp > XFER_CHUNK)
+        return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
+    const size_t total = flat ? width * rows : rows;                 // bytes or rows
+    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;          // per chunk
+    int k = 0;
+    for (size_t done = 0; done < total; k++) {
+        lumahip_ctx::Stage &st = c->stage_up[k & 1];
+        int rc = stage_ready(c, st);
+        if (rc)
+            return rc;
+        const size_t n = total - done < per ? total - done : per;
+        size_t bytes;
+        if (flat) {
+            memcpy(st.h, (const unsigned char *)src + done, n);
+            bytes = n;
+        } else {
+            for (size_t r = 0; r < n; r++)
+                memcpy(st.h + r * dp, (const unsigned char *)src + (done + r) * hp, width);
+            bytes = (n - 1) * dp + width;
+        }
+        HIPCHK(c, hipMemcpyAsync((unsigned char *)dst + done * (flat ? 1 : dp), st.h, bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(st.ev, s));
+        st.pending = true;
+        done += n;
+    }
+    return LUMAHIP_OK;
+}
+
+static int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    return xfer_h2d_2d(c, dst, bytes, src, bytes, bytes, 1, s);
+}
+
+// Device -> host.  Pinned destination: queued on `s`, the caller synchronises.  Pageable destination: the data is in
+// `dst` when the call returns (everything queued on `s` before it has completed by then).
+static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, size_t dp, size_t width, size_t rows, hipStream_t s)
+{
+    if (!width || !rows)
+        return LUMAHIP_OK;
+    if (host_range_is_pinned(dst, (rows - 1) * hp + width)) {
+        if (dp == width && hp == width)
+            HIPCHK(c, hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToHost, s));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dst, hp, src, dp, width, rows, hipMemcpyDeviceToHost, s));
+        return LUMAHIP_OK;
+    }
+    const bool flat = (dp == width && hp == width);
+    if (!flat && dp > XFER_CHUNK)
+        return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
+    const size_t total = flat ? width * rows : rows;
+    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;
+    size_t prev_done = 0, prev_n = 0;
+    int k = 0;
+    auto drain = [&](lumahip_ctx::Stage &st, size_t at, size_t n) -> int {
+        HIPCHK(c, hipEventSynchronize(st.ev));
+        st.pending = false;
+        if (flat) {
+            memcpy((unsigned char *)dst + at, st.h, n);
+        } else {
+            for (size_t r = 0; r < n; r++)
+                memcpy((unsigned char *)dst + (at + r) * hp, st.h + r * dp, width);
+        }
+        return LUMAHIP_OK;
+    };
+    for (size_t done = 0; done < total; k++) {
+        lumahip_ctx::Stage &st = c->stage_dn[k & 1];
+        int rc = stage_ready(c, st);
+        if (rc)
+            return rc;
+        const size_t n = total - done < per ? total - done : per;
+        const size_t bytes = flat ? n : (n - 1) * dp + width;
+        HIPCHK(c, hipMemcpyAsync(st.h, (const unsigned char *)src + done * (flat ? 1 : dp), bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(st.ev, s));
+        st.pending = true;
+        if (k > 0 && (rc = drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n)))
+            return rc;
+        prev_done = done;
+        prev_n = n;
+        done += n;
+    }
+    return drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n);
+}
+
+static int xfer_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    return xfer_d2h_2d(c, dst, bytes, src, bytes, bytes, 1, s);
+}
+
+// a few floats from the device: through the pinned scratch, synchronous
+static int read_small(lumahip_ctx *c, float *dst, const float *src_dev, int n, hipStream_t s)
+{
+    if (!c->h_small)
+        HIPCHK(c, hipHostMalloc((void **)&c->h_small, 64 * sizeof(float), hipHostMallocDefault));
+    HIPCHK(c, hipMemcpyAsync(c->h_small, src_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(dst, c->h_small, (size_t)n * sizeof(float));
+    return LUMAHIP_OK;
+}
+
 static int ensure(lumahip_ctx *c, void **p, size_t *cap, size_t need)
 {
     if (*cap >= need)
@@ -819,8 +989,9 @@ static int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned
     hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, c->stream, chan0_dev, n, c->d_stats);
     HIPCHK(c, hipGetLastError());
     float sum = 0.0f;
-    HIPCHK(c, hipMemcpyAsync(&sum, c->d_stats, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = read_small(c, &sum, c->d_stats, 1, c->stream);
+    if (rc)
+        return rc;
     *mean_host = sum / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
     return LUMAHIP_OK;
 }
@@ -893,24 +1064,26 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         return rc;
     if (!c->d_stats)
         HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
-    HIPCHK(c, hipMemcpyAsync(c->d_frame, rgb, nfl * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
+        return rc;
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
     const size_t pfs[3] = {0, 0, 0};
     rc = encode_frames_device_impl(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
     if (rc)
         return rc;
     for (int p = 0; p < 3; p++)
-        HIPCHK(c, hipMemcpy2DAsync(planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p],
-                                   hipMemcpyDeviceToHost, c->stream));
-    float st[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+            return rc;
     if (transformed_out) {
         rc = lumahip_transform_color_space_device(c, c->d_frame, nfl, 1, w, h, 1, sc);
         if (rc)
             return rc;
-        HIPCHK(c, hipMemcpyAsync(transformed_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = xfer_d2h(c, transformed_out, c->d_frame, nfl * sizeof(float), c->stream)))
+            return rc;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float st[3] = {0, 0, 0};
+    if ((rc = read_small(c, st, c->d_stats, 3, c->stream)))  // synchronises the stream
+        return rc;
     if (mean_lum) {
         *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
         if (mean_near_threshold(*mean_lum))  // d_frame holds the caller's frame, or already its transformed version
@@ -950,13 +1123,14 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
         return rc;
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
     for (int p = 0; p < 3; p++)
-        HIPCHK(c, hipMemcpy2DAsync(dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p],
-                                   hipMemcpyHostToDevice, c->stream));
+        if ((rc = xfer_h2d_2d(c, dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+            return rc;
     const size_t pfs[3] = {0, 0, 0};
     rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl, DisplayParams(), cs_eff);
     if (rc)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(rgb_out, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = xfer_d2h(c, rgb_out, c->d_frame, nfl * sizeof(float), c->stream)))
+        return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
 }
@@ -1032,6 +1206,21 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         return rc;
     hipStream_t saved = c->stream;
     const size_t pfs[3] = {0, 0, 0};
+    // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched: with pageable planes the fetch
+    // blocks the host (xfer_d2h_2d), and this order keeps the GPU busy with frame i meanwhile.
+    auto fetch = [&](unsigned i) -> int {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        int r = LUMAHIP_OK;
+        for (int p = 0; p < 3 && r == LUMAHIP_OK; p++)
+            r = xfer_d2h_2d(c, planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h);
+        if (r)
+            return r;
+        (void)hipMemcpyAsync(c->h_stats + 3 * (size_t)i, sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        return LUMAHIP_OK;
+    };
     for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
         lumahip_ctx::Slot &sl = c->slot[i % 3];
         unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
@@ -1040,10 +1229,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
             (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);
             (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
         }
-        if (hipMemcpyAsync(sl.d_frame, rgb[i], nfl * sizeof(float), hipMemcpyHostToDevice, c->s_h2d) != hipSuccess) {
-            rc = fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+        if ((rc = xfer_h2d(c, sl.d_frame, rgb[i], nfl * sizeof(float), c->s_h2d)))
             break;
-        }
         (void)hipEventRecord(sl.h2d, c->s_h2d);
         (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
         c->stream = c->s_kern;
@@ -1052,14 +1239,11 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         if (rc)
             break;
         (void)hipEventRecord(sl.kern, c->s_kern);
-        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
-        for (int p = 0; p < 3; p++)
-            if (hipMemcpy2DAsync(planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p],
-                                 hipMemcpyDeviceToHost, c->s_d2h) != hipSuccess)
-                rc = fail(c, LUMAHIP_ERR_HIP, "D2H copy of frame %u failed", i);
-        (void)hipMemcpyAsync(c->h_stats + 3 * (size_t)i, sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
-        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        if (i >= 1)
+            rc = fetch(i - 1);
     }
+    if (rc == LUMAHIP_OK)
+        rc = fetch(nframes - 1);
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -1068,8 +1252,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
             mean_lum[i] = c->h_stats[3 * (size_t)i] / (float)((int)w * (int)h);
             if (mean_near_threshold(mean_lum[i])) {  // rare: redo this frame's sum in the reference's order
-                if (hipMemcpyAsync(c->slot[0].d_frame, rgb[i], nfl * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
-                    return fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+                if ((rc = xfer_h2d(c, c->slot[0].d_frame, rgb[i], nfl * sizeof(float), c->stream)))
+                    return rc;
                 rc = mean_luminance_reference_impl(c, c->slot[0].d_frame, w, h, sc, c->q.cs, &mean_lum[i]);
             }
         }
@@ -1100,6 +1284,15 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
         return rc;
     hipStream_t saved = c->stream;
     const size_t pfs[3] = {0, 0, 0};
+    auto fetch = [&](unsigned i) -> int {  // as in lumahip_encode_frames_host: frame i-1 is fetched after frame i is queued
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        int r = xfer_d2h(c, rgb_out[i], sl.d_frame, nfl * sizeof(float), c->s_d2h);
+        if (r)
+            return r;
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        return LUMAHIP_OK;
+    };
     for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
         lumahip_ctx::Slot &sl = c->slot[i % 3];
         unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
@@ -1107,10 +1300,8 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
             (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);   // planes of frame i-3 consumed
             (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);   // floats of frame i-3 copied out
         }
-        for (int p = 0; p < 3; p++)
-            if (hipMemcpy2DAsync(dp[p], stride[p], planes[3 * i + p], stride[p], L.row_bytes[p], L.rows[p],
-                                 hipMemcpyHostToDevice, c->s_h2d) != hipSuccess)
-                rc = fail(c, LUMAHIP_ERR_HIP, "H2D copy of frame %u failed", i);
+        for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++)
+            rc = xfer_h2d_2d(c, dp[p], stride[p], planes[3 * i + p], stride[p], L.row_bytes[p], L.rows[p], c->s_h2d);
         if (rc)
             break;
         (void)hipEventRecord(sl.h2d, c->s_h2d);
@@ -1121,11 +1312,11 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
         if (rc)
             break;
         (void)hipEventRecord(sl.kern, c->s_kern);
-        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
-        if (hipMemcpyAsync(rgb_out[i], sl.d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h) != hipSuccess)
-            rc = fail(c, LUMAHIP_ERR_HIP, "D2H copy of frame %u failed", i);
-        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        if (i >= 1)
+            rc = fetch(i - 1);
     }
+    if (rc == LUMAHIP_OK)
+        rc = fetch(nframes - 1);
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -1151,21 +1342,25 @@ extern "C" int lumahip_transform_color_space_host(lumahip_ctx *c, float *frame, 
     if (rc)
         return rc;
     if (npad == n) {
-        HIPCHK(c, hipMemcpyAsync(c->d_frame, frame, nfl * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if ((rc = xfer_h2d(c, c->d_frame, frame, nfl * sizeof(float), c->stream)))
+            return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(c->d_frame, 0, 3 * npad * sizeof(float), c->stream));
         for (int ch = 0; ch < 3; ch++)
-            HIPCHK(c, hipMemcpyAsync(c->d_frame + ch * npad, frame + ch * n, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            if ((rc = xfer_h2d(c, c->d_frame + ch * npad, frame + ch * n, n * sizeof(float), c->stream)))
+                return rc;
     }
     // the kernel addresses channels at chan_stride = (w*h); present the padded buffer as a (npad x 1) frame
     rc = lumahip_transform_color_space_device(c, c->d_frame, 3 * npad, 1, (unsigned)npad, 1, toCs, sc);
     if (rc)
         return rc;
     if (npad == n) {
-        HIPCHK(c, hipMemcpyAsync(frame, c->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = xfer_d2h(c, frame, c->d_frame, nfl * sizeof(float), c->stream)))
+            return rc;
     } else {
         for (int ch = 0; ch < 3; ch++)
-            HIPCHK(c, hipMemcpyAsync(frame + ch * n, c->d_frame + ch * npad, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = xfer_d2h(c, frame + ch * n, c->d_frame + ch * npad, n * sizeof(float), c->stream)))
+                return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
@@ -1185,10 +1380,12 @@ static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsig
     int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, 2 * n * sizeof(float));
     if (rc)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_arr, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = xfer_h2d(c, c->d_arr, in, n * sizeof(float), c->stream)))
+        return rc;
     if ((rc = array_launch(c, c->d_arr, c->d_arr + n, n, ch, quant)))
         return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_arr + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = xfer_d2h(c, out, c->d_arr + n, n * sizeof(float), c->stream)))
+        return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
 }
@@ -1362,7 +1559,9 @@ extern "C" int lumahip_memcpy_h2d(lumahip_ctx *c, void *dst, const void *src, si
     if (!c)
         return LUMAHIP_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = xfer_h2d(c, dst, src, bytes, c->stream);
+    if (rc)
+        return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
 }
@@ -1372,7 +1571,9 @@ extern "C" int lumahip_memcpy_d2h(lumahip_ctx *c, void *dst, const void *src, si
     if (!c)
         return LUMAHIP_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    int rc = xfer_d2h(c, dst, src, bytes, c->stream);
+    if (rc)
+        return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LUMAHIP_OK;
 }

@@ -64,6 +64,25 @@ struct PowfTables {
 
 static const PowfTables kPowfTablesHost = {LH_POWF_LOG2_TAB, LH_POWF_EXP2_TAB};
 
+// The LDS copy the kernels use adds a "wide" log2 table: entry (k & 127) * 16 + i holds {invc[i], logc[i] + (double)k}
+// for the binary exponents k in [-64, 63] -- the two operands log2_inline needs, so that ONE 16-byte LDS read keyed by
+// bits 19..29 of (ix - OFF) replaces the 16-entry read, the arithmetic shift, the int -> double conversion and the fp64
+// add `logc + (double)k` (10 issue cycles per powf on gfx950; the sum is the same single rounding, done when the table
+// is filled).  Arguments outside 2^-64 .. 2^64 take the complete function (pw_range_key).
+struct PowfTablesWide : PowfTables {
+    double wide[2048][2];
+};
+static_assert(sizeof(PowfTablesWide) == sizeof(PowfTables) + 32768, "layout");
+
+// entry e of the wide table from the 16-entry table: e = (k & 127) * 16 + i
+LH_HD void pw_wide_entry(int e, const double (&lt)[16][2], double &invc, double &y0)
+{
+    const int kk = e >> 4, i = e & 15;
+    const int k = kk < 64 ? kk : kk - 128;
+    invc = lt[i][0];
+    y0 = lt[i][1] + (double)k;  // the one rounding of log2_inline's `logc + (double) k`
+}
+
 LH_HD uint32_t pw_asuint(float f)
 {
     uint32_t u;
@@ -198,6 +217,38 @@ LH_HD float powf_glibc(float x, float y, const Tab &T)
     return (float)e;
 }
 
+// log2_inline's table operands for tmp = ix - OFF: {invc, logc + (double)k}
+LH_HD void pw_log2_operands(const PowfTables &T, uint32_t tmp, double &invc, double &y0)
+{
+    const int i = (tmp >> (23 - 4)) % 16;
+    const int k = (int32_t)(tmp & 0xff800000u) >> 23;
+    invc = T.log2_tab[i][0];
+    y0 = T.log2_tab[i][1] + (double)k;
+}
+LH_HD void pw_log2_operands(const PowfTablesWide &T, uint32_t tmp, double &invc, double &y0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_bfe_u32, then one v_lshl_add_u32 forms the LDS address; written as a builtin or as shifts the compiler turns
+    // it into shift + and + add (three instructions)
+    uint32_t e;
+    asm("v_bfe_u32 %0, %1, 19, 11" : "=v"(e) : "v"(tmp));
+#else
+    const uint32_t e = (tmp >> (23 - 4)) & 2047u;
+#endif
+    invc = T.wide[e][0];
+    y0 = T.wide[e][1];
+}
+// Range key of an argument's bits: powf_regular applies iff key < pw_range_limit (unsigned) -- x a positive normal
+// finite float, and with the wide table also 2^-64 <= x / 0.7 < 2^64.  One unsigned subtract; callers with many
+// arguments keep a running unsigned maximum of the keys and compare once.
+LH_HD uint32_t pw_range_key(const PowfTables &, uint32_t ix) { return ix - 0x00800000u; }
+LH_HD uint32_t pw_range_limit(const PowfTables &) { return 0x7f000000u; }
+LH_HD uint32_t pw_range_key(const PowfTablesWide &, uint32_t ix) { return ix - (0x3f330000u - (64u << 23)); }
+LH_HD uint32_t pw_range_limit(const PowfTablesWide &) { return 128u << 23; }
+// bits of the smallest argument the straight-line form accepts (for "x is +0 or >= this" tests)
+LH_HD uint32_t pw_range_low(const PowfTables &) { return 0x00800000u; }
+LH_HD uint32_t pw_range_low(const PowfTablesWide &) { return 0x3f330000u - (64u << 23); }
+
 // Straight-line form for the arguments the PQ transforms see almost always: x positive, normal and finite (or +0
 // when ZERO) with |y*log2(x)| < 126; y is one of the four positive PQ exponents.  For those arguments it performs
 // exactly the arithmetic of powf_glibc above (same operations, same order) without any of its branches; for
@@ -216,18 +267,16 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
     if (ZERO)
         zero = (ix == 0);
     if (CHECK_X)
-        slow = slow || (!zero && (ix - 0x00800000u >= 0x7f800000u - 0x00800000u));
+        slow = slow || (!zero && (pw_range_key(T, ix) >= pw_range_limit(T)));
     const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
                  A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
     const uint32_t tmp = ix - 0x3f330000u;
-    const int i = (tmp >> (23 - 4)) % 16;
     const uint32_t top = tmp & 0xff800000u;
     const uint32_t iz = ix - top;
-    const int k = (int32_t)top >> 23;
-    const double invc = T.log2_tab[i][0], logc = T.log2_tab[i][1];
+    double invc, y0;
+    pw_log2_operands(T, tmp, invc, y0);
     const double z = (double)pw_asfloat(iz);
     const double r = __builtin_fma(z, invc, -1.0);
-    const double y0 = logc + (double)k;
     const double r2 = r * r;
     double yy = __builtin_fma(A0, r, A1);
     const double p = __builtin_fma(A2, r, A3);

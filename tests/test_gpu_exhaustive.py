@@ -13,6 +13,8 @@
    The other side of each comparison is the literal bisection kernel on the GPU (LUMAHIP_FORCE_LITERAL), itself
    pinned against the oracle / the reference fixtures in test_gpu_parity.py and spot-checked here against the oracle.
 2. The device powf (pow_glibc.hpp) equals the host libm powf for every non-negative float, for the four PQ exponents.
+3. The YCbCr decode kernel (8 straight-line powf per pixel with range arguments stated in luma_device.hpp) equals the
+   oracle for EVERY (Y, Cb, Cr) code triple of the HDR10 recipe: 1024^3 pixels through 4:4:4 16-bit planes.
 """
 import os
 
@@ -269,3 +271,34 @@ def test_device_powf_equals_host_libm_for_every_nonnegative_float(oracle_mod, re
             bad, fb = o.powf_compare(out[:1 << 20].cpu().numpy(), chunk * n, y)
             assert bad == 0, ("y=%r first mismatch at bits 0x%08x" % (y, fb))
     assert total_bad == 0
+
+
+def test_ycbcr_decode_every_code_triple_of_the_hdr10_recipe(oracle_mod):
+    """(3): PQ 10-bit / YCbCr 10-bit chroma, max 1000 cd/m2, preScaling 20 (README.md:46-59 of the reference; BASELINE
+    configs[2]).  Frame k holds Y code k everywhere, Cb = row index, Cr = column index; profile 3 (4:4:4) so that every
+    pixel carries its own triple.  Decoded floats must equal the oracle's bit for bit (0 ulp)."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    cfg = (o.PTF_PQ, 10, o.CS_YCBCR, 10, 1000.0, 0.01)
+    q = L.LumaQuantizer()
+    q.setQuantizer(*cfg)
+    orc = o.Oracle(*cfg)
+    w = h = 1024
+    _, hs, st, bps = L.plane_geometry(w, h, 3)
+    assert bps == 2 and tuple(hs) == (h, h, h)
+
+    def plane(codes):
+        buf = np.zeros((h, st[0]), dtype=np.uint8)
+        buf[:, :2 * w] = codes.astype("<u2").view(np.uint8).reshape(h, 2 * w)
+        return buf
+
+    cb = plane(np.repeat(np.arange(h, dtype=np.uint16)[:, None], w, axis=1))
+    cr = plane(np.repeat(np.arange(w, dtype=np.uint16)[None, :], h, axis=0))
+    nthreads = os.cpu_count() or 1
+    # the decoder clamps codes above maxVal, so 1024 (one past the last code) is included as well
+    for k in range(1025):
+        planes = [plane(np.full((h, w), k, dtype=np.uint16)), cb, cr]
+        got = q.ctx.decode_frame(planes, st, w, h, 20.0, 3)
+        exp = orc.decode(planes, st, w, h, 20.0, 3, threads=nthreads)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        assert bool(same.all()), (k, np.argwhere(~same)[:4].tolist())

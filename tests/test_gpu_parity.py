@@ -421,6 +421,27 @@ def test_pipelined_batch_host_entry_points(L, oracle_mod):
         assert all(np.array_equal(a, b) for a, b in zip(p2[i], e))
 
 
+def test_pageable_buffers_are_staged_in_chunks_with_padded_strides(L, oracle_mod):
+    """Pageable caller memory moves through 8 MiB pinned chunks (lumahip_capi.hip: xfer_h2d_2d / xfer_d2h_2d).  A 4K
+    frame with row strides wider than the rows makes every plane a multi-chunk, row-by-row transfer in both directions;
+    results equal the oracle's and the padding bytes of the caller's planes are never written."""
+    o = oracle_mod
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    w, h = 3840, 2160
+    f = o.synth_frame(w, h, frame=21)
+    strides = (2 * w + 96, w + 32, w + 32)
+    planes, st, _ = q.ctx.encode_frame(f, 1.0, 2, strides=strides)
+    assert tuple(st) == strides
+    e, est, _ = orc.encode(f.copy(), 1.0, 2, threads=8)
+    rb = (2 * w, w, w)
+    for p in range(3):
+        ep = o.packed_rows(e[p], rb[p])
+        assert np.array_equal(planes[p][:, :rb[p]].reshape(-1), np.asarray(ep).reshape(-1)), p
+        assert not planes[p][:, rb[p]:].any(), p   # padding untouched (the buffers start zeroed)
+    got = q.ctx.decode_frame(planes, st, w, h, 1.0, 2)
+    assert same_bits(got, orc.decode(e, est, w, h, 1.0, 2, threads=8))
+
+
 @pytest.mark.parametrize("rgb,codes", [
     ((1, 1, 1), (307, 81, 192)), ((100, 100, 100), (1040, 81, 192)), ((10000, 0, 0), (1707, 185, 214)),
     ((0, 10000, 0), (1975, 51, 231)), ((0, 0, 10000), (1466, 72, 65)), ((0, 0, 0), (3, 86, 194)),

@@ -66,7 +66,7 @@ int main(int argc, char **argv)
     q.lut = d_lut; q.rec = d_rec; q.lut_len = (int)n; q.pad = (int)(padded.size() - n);
     q.maxVal = (int)n - 1; q.mode = LUT_THRESH_LDS; q.shift = ix.shift; q.kmin = ix.kmin; q.nbuckets = ix.nbuckets;
     q.maxC = EXP_CS == 2 ? 1023.0f : 255.0f; q.cs = EXP_CS; q.Lmax = maxLum;
-    const size_t lds = (EXP_LM == 3 ? (((size_t)ix.nbuckets * 4 + 15) & ~(size_t)15) : 0) + (EXP_CS == 2 ? sizeof(PowfTables) : 0);
+    const size_t lds = (EXP_LM == 3 ? (((size_t)ix.nbuckets * 4 + 15) & ~(size_t)15) : 0) + (EXP_CS == 2 ? sizeof(PowfTablesWide) : 0);
 
     const int W = 3840, H = 2160, B = 20;
     const size_t n3 = (size_t)3 * W * H;

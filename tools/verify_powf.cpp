@@ -6,6 +6,9 @@
 // n = 0.1593f, m = 78.8438f, 1.0f/m, 1.0f/n) every non-negative float bit pattern 0 .. 0x7f800000 (zero,
 // subnormals, normals, +inf) plus NaNs and a sweep of negatives is evaluated with the restatement and
 // with libm powf; results must be bit-identical (NaN == NaN).  stride > 1 samples every stride-th pattern.
+// The straight-line form the kernels use (powf_regular with its "redo with the complete function" flag) is checked
+// on the same arguments with both table layouts: the 16-entry log2 table and the wide LDS table (one entry per
+// binary exponent in [-64, 63] x table index), filled by the function the kernels fill it with.
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -34,13 +37,23 @@ int main(int argc, char **argv)
     const float ys[4] = {n, m, one / m, one / n};
     const unsigned nt = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4;
     uint64_t total_bad = 0, total = 0;
+    static lh::PowfTablesWide wide;
+    {
+        const double lt[16][2] = LH_POWF_LOG2_TAB;
+        const uint64_t et[32] = LH_POWF_EXP2_TAB;
+        memcpy(wide.log2_tab, lt, sizeof lt);
+        memcpy(wide.exp2_tab, et, sizeof et);
+        for (int e = 0; e < 2048; e++)
+            lh::pw_wide_entry(e, lt, wide.wide[e][0], wide.wide[e][1]);
+    }
+    std::atomic<uint64_t> fast16{0}, fastw{0};
     for (int e = 0; e < 4; e++) {
         const float y = ys[e];
         std::atomic<uint64_t> bad{0}, cnt{0};
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
-                uint64_t b = 0, c = 0;
+                uint64_t b = 0, c = 0, f1 = 0, f2 = 0;
                 for (uint64_t u = t * stride; u <= 0xffffffffull; u += nt * stride) {
                     // all non-negative patterns; of the negative / NaN half only every 4096th
                     if (u > 0x7f800000ull && (u & 0xfff) != 0 && stride == 1)
@@ -54,9 +67,22 @@ int main(int argc, char **argv)
                             fprintf(stderr, "MISMATCH y=%a x=%a (0x%08x): restated %a libm %a\n", y, x, (unsigned)u, a, r);
                         b++;
                     }
+                    // straight-line form: wherever it does not raise `slow` its result must be libm's
+                    bool s16 = false, sw = false;
+                    const float f16 = lh::powf_regular<true, true, true>(x, y, lh::kPowfTablesHost, s16);
+                    const float fw = lh::powf_regular<true, true, true>(x, y, wide, sw);
+                    if ((!s16 && !same(f16, r)) || (!sw && !same(fw, r))) {
+                        if (b < 5)
+                            fprintf(stderr, "MISMATCH (straight-line) y=%a x=%a (0x%08x): %a / %a libm %a\n", y, x, (unsigned)u, f16, fw, r);
+                        b++;
+                    }
+                    f1 += !s16;
+                    f2 += !sw;
                 }
                 bad += b;
                 cnt += c;
+                fast16 += f1;
+                fastw += f2;
             });
         for (auto &x : th)
             x.join();
@@ -65,6 +91,8 @@ int main(int argc, char **argv)
         total_bad += bad;
         total += cnt;
     }
+    printf("straight-line form applied to %llu (16-entry table) / %llu (wide table) of them\n",
+           (unsigned long long)fast16.load(), (unsigned long long)fastw.load());
     printf("TOTAL %llu arguments, %llu mismatches\n", (unsigned long long)total, (unsigned long long)total_bad);
     return total_bad ? 1 : 0;
 }
