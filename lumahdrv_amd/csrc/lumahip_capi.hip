@@ -17,7 +17,12 @@
 
 using namespace lh;
 
-static constexpr size_t LUMAHIP_REC_LDS_MAX = 72 * 1024;
+// Largest search table (encode: threshold records, decode: the luminance table) a workgroup stages in LDS; beyond it
+// the table is read from global memory (L2-resident).  gfx950 has 160 KiB of LDS per CU; tables beyond 53 KiB run as one
+// or two 1024-thread workgroups per CU -- for the 136 KiB of PQ 13-bit records that is still twice as fast as gathering
+// them from L2 (346 against 182 Gpixel/s, profiles/r02_perf_matrix.txt).  LUMAHIP_LDS_TABLE_MAX_KB overrides it.
+static constexpr size_t LUMAHIP_LDS_TABLE_MAX_DEFAULT = 144 * 1024;
+static constexpr size_t LUMAHIP_LDS_PER_WORKGROUP = 160 * 1024;
 
 struct lumahip_ctx {
     int device = 0;
@@ -69,6 +74,7 @@ struct lumahip_ctx {
     bool block_forced = false;
     bool allow_alias = false;  // LUMAHIP_ALLOW_ALIASED_FRAMES=1: measurement tools alias all frames of a batch onto one
     int blocks_per_cu = 0;  // 0 = occupancy query
+    size_t lds_table_max = LUMAHIP_LDS_TABLE_MAX_DEFAULT;
 };
 
 static int fail(lumahip_ctx *c, int code, const char *fmt, ...)
@@ -142,6 +148,11 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
         c->blocks_per_cu = atoi(e);
     if (const char *e = getenv("LUMAHIP_ALLOW_ALIASED_FRAMES"))
         c->allow_alias = atoi(e) != 0;
+    if (const char *e = getenv("LUMAHIP_LDS_TABLE_MAX_KB")) {
+        const long kb = atol(e);
+        if (kb >= 0 && kb <= 152)
+            c->lds_table_max = (size_t)kb * 1024;
+    }
     *out = c;
     return LUMAHIP_OK;
 }
@@ -227,16 +238,21 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     // Search index.  Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit
-    // LUMAHIP_REC_LDS_MAX (two 1024-thread workgroups per CU then still fit the 160 KiB), else in global memory
+    // lds_table_max, else in global memory
     // (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table)
     // runs the reference's bisection literally.  LUMAHIP_FORCE_LITERAL is the tests' hook for that path.
     c->tix = ThreshIndex();
-    c->lut_in_lds = (n <= 4096 && bitdepthC <= 12);  // decode side: luminance table (+ Lu'v' chroma table) staged in LDS
+    // decode side: luminance table (+ Lu'v' chroma table, + the powf tables for YCbCr) staged in LDS
+    const size_t powf_b = (cs == CS_YCBCR) ? sizeof(PowfTablesWide) : 0;
+    c->lut_in_lds = bitdepthC <= 12 && (n + 4) * sizeof(float) <= std::max<size_t>(c->lds_table_max, 16 * 1024 + 16) &&
+                    (n + 4) * sizeof(float) + ((size_t)4 << bitdepthC) + 64 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP;
     int mode = n <= 4096 ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
     if (!getenv("LUMAHIP_FORCE_LITERAL")) {
         c->tix = build_thresh_index(lut, (int)n, 1 << 19);
         if (c->tix.ok)
-            mode = (c->tix.rec.size() * 4 <= LUMAHIP_REC_LDS_MAX) ? LUT_THRESH_LDS : LUT_THRESH_GLOBAL;
+            mode = (c->tix.rec.size() * 4 <= c->lds_table_max && c->tix.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP)
+                       ? LUT_THRESH_LDS
+                       : LUT_THRESH_GLOBAL;
     }
     const size_t lut_floats = (n + 1 + 3) & ~(size_t)3;  // NaN padding up to a multiple of 16 bytes
     std::vector<float> padded(lut_floats, __builtin_nanf(""));

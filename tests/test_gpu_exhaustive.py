@@ -23,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12)]
+TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12), (1, 13)]   # (1, 13): 136 KiB of records, one workgroup per CU
 
 
 def _pair(L, ptf, bits, cs):
@@ -133,14 +133,18 @@ def test_encode_kernel_search_equals_bisection_for_every_float(oracle_mod, ptf, 
 
 @pytest.mark.parametrize("ptf,bits", [(1, 13), (2, 14), (1, 16)])
 def test_global_memory_records_sampled(oracle_mod, ptf, bits):
-    """Tables deeper than 12 bits: records in global memory (mode 4) where the table qualifies, against the literal
-    bisection on the global-memory table (slow: 13-16 dependent loads per value), on 2^22 consecutive bit patterns
-    from every 2^27 boundary plus 2^26 random patterns."""
+    """Tables whose records do not fit LDS (here: the LDS limit forced to 0): records in global memory (mode 4) where
+    the table qualifies, against the literal bisection on the global-memory table (slow: 13-16 dependent loads per
+    value), on 2^22 consecutive bit patterns from every 2^27 boundary plus 2^26 random patterns."""
     import torch
     import lumahdrv_amd as L
     dev = torch.device("cuda:0")
     lut = L.build_lut(ptf, bits, 1e4, 0.005)
-    fast = L.Context(0)
+    os.environ["LUMAHIP_LDS_TABLE_MAX_KB"] = "0"
+    try:
+        fast = L.Context(0)
+    finally:
+        os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
     fast.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
     if fast.quantizer_info()["mode"] != 4:
         pytest.skip("table does not qualify for records (mode %d)" % fast.quantizer_info()["mode"])

@@ -151,8 +151,9 @@ def test_survey_testframe_digests(L, oracle_mod):
 
 
 def test_literal_and_global_lut_modes(L, oracle_mod):
-    """a non-monotone table must take the literal bisection path, a 13-bit table the global-memory path;
-    both still bit-exact against the oracle's (literal) search"""
+    """a non-monotone table must take the literal bisection path; a 13-bit table has 136 KiB of records (LDS, one
+    workgroup per CU) or, with a lower LDS limit, reads them from global memory; all bit-exact against the oracle's
+    (literal) search"""
     o = oracle_mod
     rng = np.random.default_rng(5)
     # (a) non-monotone 11-bit table, as a decoder may be handed in attachment 434
@@ -169,13 +170,21 @@ def test_literal_and_global_lut_modes(L, oracle_mod):
     e, _, _ = orc.encode(f.copy(), 1.0, 2)
     assert all(np.array_equal(a, b) for a, b in zip(planes, e))
     assert same_bits(q.ctx.decode_frame(planes, st, 64, 32, 1.0, 2), orc.decode(e, st, 64, 32, 1.0, 2))
-    # (b) 13-bit PQ table: its threshold records do not fit LDS -> records in global memory (mode 4); the same table
-    #     made non-monotone -> the reference's bisection on the global-memory table (mode 2)
+    # (b) 13-bit PQ table: threshold records in LDS (mode 3); the same table made non-monotone -> the reference's
+    #     bisection on the global-memory table (mode 2)
     lut13 = L.build_lut(L.PTF_PQ, 13).copy()
     bad13 = lut13.copy()
     bad13[3000:3010] = bad13[3000:3010][::-1]
-    for table, mode in ((None, 4), (bad13, 2)):
-        q2 = L.LumaQuantizer()
+    #     LUMAHIP_LDS_TABLE_MAX_KB moves the boundary: 64 -> records in global memory (mode 4), the decode kernels'
+    #     32 KiB luminance table still in LDS; 0 -> the decode kernels read theirs from global memory as well
+    for table, mode, kb in ((None, 3, None), (bad13, 2, None), (None, 4, "64"), (None, 4, "0")):
+        os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
+        if kb is not None:
+            os.environ["LUMAHIP_LDS_TABLE_MAX_KB"] = kb
+        try:
+            q2 = L.LumaQuantizer()
+        finally:
+            os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
         q2.setQuantizer(L.PTF_PQ, 13, L.CS_XYZ, 8, 1e4, 0.005, mapping_override=table)
         assert q2.ctx.quantizer_info()["mode"] == mode
         orc2 = o.Oracle(o.PTF_PQ, 13, o.CS_XYZ, 8, 1e4, 0.005)
