@@ -242,22 +242,37 @@ LH_DEVS void xform_fwd<CS_XYZ>(float r, float g, float b, const XformConst &k, f
 template <>
 LH_DEVS void xform_fwd<CS_LUV>(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2)
 {
-    // a NaN among r, g, b makes X, Y, Z NaN; clamp_xyz passes it on and it then propagates through the rest of
-    // the arithmetic exactly as it does in the reference (Y -> code maxVal, u', v' -> code maxC)
-    const float X = clamp_xyz((0.412424f * r + 0.357579f * g) + 0.180464f * b);
+    // A NaN among r, g, b (or an inf - inf among the products) makes X, Y and Z NaN together: the three rows have the
+    // same pattern of positive coefficients.  Y is clamped NaN-propagating (clamp_xyz) and carries the NaN into c0
+    // (-> code maxVal) and, through `sum`, into x, y, den, c1 and c2 (-> code maxC) exactly as in the reference.  X and Z
+    // only ever reach the outputs through `sum` and x, so for them the one-instruction median clamp is enough: for
+    // every non-NaN value (+-inf included) it IS std::max(std::min(v, 1e8f), 1e-4f), and what it returns for a NaN is
+    // irrelevant because Y's NaN dominates everything computed from it.
+    const float X = __builtin_amdgcn_fmed3f((0.412424f * r + 0.357579f * g) + 0.180464f * b, 0.0001f, 100000000.0f);
     const float Y = clamp_xyz((0.212656f * r + 0.715158f * g) + 0.072186f * b);
-    const float Z = clamp_xyz((0.019332f * r + 0.119193f * g) + 0.950444f * b);
+    const float Z = __builtin_amdgcn_fmed3f((0.019332f * r + 0.119193f * g) + 0.950444f * b, 0.0001f, 100000000.0f);
     const float sum = (X + Y) + Z;
     // X,Y,Z in [1e-4,1e8] (or NaN) after the clamp, sum in [3e-4,3e8]: div_nr is exact here
     const float rs = rcp_nr(sum);
     const float x = div_nr_r(X, sum, rs);
     const float y = div_nr_r(Y, sum, rs);
-    // x,y in (0,1], x+y<=1+ulp: den = 3 - 2x + 12y in [1,15]; numerators in [1e-12,9]
+    // x,y in (0,1], x+y<=1+ulp: den = 3 - 2x + 12y in [1,15]; numerators in [1e-12,9].
+    // (-2.0f*x) is exact (a power of two), so (-2x) + t rounds once: the fused form is the same float.
+#ifdef LH_NO_FAST_DIV
     const float den = ((-2.0f * x) + 12.0f * y) + 3.0f;
+#else
+    const float den = __builtin_fmaf(-2.0f, x, 12.0f * y) + 3.0f;
+#endif
     const float rd = rcp_nr(den);
-    // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410: div_255_pos is exact
+    // (4x/den)*410 and (9y/den)*410 are > 0 and <= 9*410: div_255_pos is exact.
+    // 4.0f*x is exact as well and scaling by 4 commutes with the rounding of the quotient (x/den >= 2e-14, far from the
+    // denormals), so RN(RN(4x/den) * 410) = RN(RN(x/den) * 1640): one multiplication less.
     c0 = Y;  // >= 1e-4, or a NaN of either sign: the luminance search is told so (NONNEG)
+#ifdef LH_NO_FAST_DIV
     c1 = div_255_pos(div_nr_r(4.0f * x, den, rd) * 410.f);
+#else
+    c1 = div_255_pos(div_nr_r(x, den, rd) * 1640.f);
+#endif
     c2 = div_255_pos(div_nr_r(9.0f * y, den, rd) * 410.f);
 }
 
@@ -527,17 +542,47 @@ struct QuantDev {
     float Lmax;
 };
 
-// colour-channel quantizer: floor(maxC*val + 0.5f) clamped with std::min / std::max,
-// src/luma_quantizer.cpp:238-241
-LH_DEV int quantize_color(float val, float maxC)
+// colour-channel quantizer: floor(maxC*val + 0.5f) clamped with std::min / std::max, src/luma_quantizer.cpp:238-241.
+// With t = maxC*val + 0.5f the reference returns max(0, min(maxC, floor(t))).  std::min(maxC, res) = (res < maxC) ? res :
+// maxC returns maxC when res is NaN -- IEEE minNum (v_min_f32); the result is then non-NaN and std::max(0.0f, .) is
+// maxNum.  Clamping BEFORE taking the integer part gives the same integer without the floor instruction: t >= maxC ->
+// maxC either way (maxC is an integer); 0 <= t < maxC -> the float -> int conversion truncates, which is floor for a
+// non-negative value; t < 0 -> floor(t) <= -1 is raised to 0, and so is t itself; NaN -> maxC by the min.
+// NONNEG: the caller guarantees val >= 0 or NaN (Lu'v' chroma), so t >= 0.5 and the max(0, .) is the identity.
+template <bool NONNEG = false>
+LH_DEV int quantize_color_t(float t, float maxC)
 {
-    float res = floorf(maxC * val + 0.5f);
-    // std::min(maxC, res) = (res < maxC) ? res : maxC returns maxC when res is NaN -- exactly IEEE minNum
-    // (v_min_f32), because the non-NaN operand is the one std::min falls back to.  The result is then
-    // non-NaN, and std::max(0.0f, t) = maxNum(0, t) for every non-NaN t (a -0 converts to code 0 either way).
+#ifdef LH_NO_FAST_DIV  // the literal form, for the A/B build
+    float res = floorf(t);
     res = __builtin_fminf(res, maxC);
     res = __builtin_fmaxf(res, 0.0f);
     return (int)res;
+#else
+    float res = __builtin_fminf(t, maxC);
+    if (!NONNEG)
+        res = __builtin_fmaxf(res, 0.0f);
+    return (int)res;
+#endif
+}
+
+template <bool NONNEG = false>
+LH_DEV int quantize_color(float val, float maxC)
+{
+    return quantize_color_t<NONNEG>(maxC * val + 0.5f, maxC);
+}
+
+// The 4:2:0 chroma sample: quantize_color(0.25f * s4, maxC) with s4 the sum of the four pixels
+// (src/luma_encoder.cpp:287-289 followed by src/luma_quantizer.cpp:238-241).  0.25f * s4 is exact (a power of two; s4 is
+// zero or far above the denormals) and so is qc = 0.25f * maxC (maxC = 2^n - 1, n <= 16), hence
+// RN(maxC * (0.25 * s4)) = RN(qc * s4): one multiplication instead of two.
+template <bool NONNEG = false>
+LH_DEV int quantize_color_sum4(float s4, float maxC, float qc)
+{
+#ifdef LH_NO_FAST_DIV
+    return quantize_color<NONNEG>(0.25f * s4, maxC);
+#else
+    return quantize_color_t<NONNEG>(qc * s4 + 0.5f, maxC);
+#endif
 }
 
 // colour-channel dequantizer: std::max(val/maxC, 1e-10f), src/luma_quantizer.cpp:261

@@ -389,19 +389,27 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
         float a1[NQ], a2[NQ];
 #pragma unroll
         for (int qd = 0; qd < NQ; qd++) {
-            // src/luma_encoder.cpp:287-289: 0.25f*(src[i] + src[i+1] + src[i+2w] + src[i+2w+1])
-            a1[qd] = 0.25f * (((c1[2 * qd] + c1[2 * qd + 1]) + c1[VW + 2 * qd]) + c1[VW + 2 * qd + 1]);
-            a2[qd] = 0.25f * (((c2[2 * qd] + c2[2 * qd + 1]) + c2[VW + 2 * qd]) + c2[VW + 2 * qd + 1]);
+            // src/luma_encoder.cpp:287-289: 0.25f*(src[i] + src[i+1] + src[i+2w] + src[i+2w+1]); the factor is applied
+            // below (LUT_ALL) or folded into the colour quantizer's scale (quantize_color_sum4)
+            a1[qd] = ((c1[2 * qd] + c1[2 * qd + 1]) + c1[VW + 2 * qd]) + c1[VW + 2 * qd + 1];
+            a2[qd] = ((c2[2 * qd] + c2[2 * qd + 1]) + c2[VW + 2 * qd]) + c2[VW + 2 * qd + 1];
         }
         int k1[NQ], k2[NQ];
         if constexpr (LUT_ALL) {
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++) {
+                a1[qd] *= 0.25f;
+                a2[qd] *= 0.25f;
+            }
             quantize_lut<LM, NQ>(a1, k1, lut, idx, a.q);
             quantize_lut<LM, NQ>(a2, k2, lut, idx, a.q);
         } else {
+            const float qc = 0.25f * maxC;
 #pragma unroll
             for (int qd = 0; qd < NQ; qd++) {
-                k1[qd] = quantize_color(a1[qd], maxC);
-                k2[qd] = quantize_color(a2[qd], maxC);
+                // Lu'v' chroma is positive or NaN (xform_fwd<CS_LUV>), so is the sum of four
+                k1[qd] = quantize_color_sum4<CS == CS_LUV>(a1[qd], maxC, qc);
+                k2[qd] = quantize_color_sum4<CS == CS_LUV>(a2[qd], maxC, qc);
             }
         }
         store_samples<NQ>(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] +
@@ -416,8 +424,8 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * VW; j++) {
-                k1[j] = quantize_color(c1[j], maxC);
-                k2[j] = quantize_color(c2[j], maxC);
+                k1[j] = quantize_color<CS == CS_LUV>(c1[j], maxC);
+                k2[j] = quantize_color<CS == CS_LUV>(c2[j], maxC);
             }
         }
 #pragma unroll
