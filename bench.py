@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
+    ap.add_argument("--placement", default="auto", choices=["auto", "off"],
+                    help="auto: device memory is taken in 2 GiB chunks, their region groups found with traffic-only launches, and the "
+                         "Y planes of the resident stream live in another group than its other buffers (lumahdrv_amd/placement.py); "
+                         "off: plain allocations")
     ap.add_argument("--profile-dir", default=os.path.join(ROOT, "profiles"),
                     help="where traffic_latest.json / valu_mix_latest.json (tools/summarize_profile.py) live")
     return ap.parse_args()
@@ -170,7 +174,7 @@ def load_profile(path, workload, px_step, sha):
     return None
 
 
-def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha):
+def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha, pool=None):
     """one workload: resident synthetic stream, encode timed (plus decode / round trip for the main one), roofline block"""
     from lumahdrv_amd.sharding import broadcast_quantizer
     ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
@@ -190,19 +194,44 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
     per_frame = n3 * 4 * (2 if main else 1) + sum(psz)     # input (+ decoded output) + planes
     free, _total = torch.cuda.mem_get_info(dev)
     want_frames = 500 if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)    # >= 4 GB of distinct input: >> 256 MB MALL
-    nbatch = max(1, min(want_frames // B, int(free * 0.8 // per_frame) // B))
+    if pool is not None:
+        from lumahdrv_amd.placement import CHUNK_BYTES, slots
+        ypc, yslot = slots(CHUNK_BYTES, B * psz[0])
+        uvpc, uvslot = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
+            pool = None
+    if pool is not None:
+        # float frames: one chunk per batch of input, one per batch of decoded output; Y planes of `ypc` batches per chunk
+        # of the Y group; U and V planes of `uvpc` batches per chunk of the other groups (lumahdrv_amd/placement.py)
+        nbatch = max(1, want_frames // B)
+        while nbatch > 1 and (nbatch * (2 if main else 1) + -(-nbatch // uvpc) > len(pool.other) or -(-nbatch // ypc) > len(pool.y)):
+            nbatch -= 1
+        src_c = pool.take_other(nbatch)
+        out_c = pool.take_other(nbatch) if main else []
+        uv_c = pool.take_other(-(-nbatch // uvpc))
+        y_c = pool.take_y(-(-nbatch // ypc))
+        for c in uv_c + y_c:
+            c.zero_()
+        vo = (B * psz[1] + (1 << 20) - 1) // (1 << 20) * (1 << 20)
+
+        def ptrs(b):
+            u = uv_c[b // uvpc].data_ptr() + (b % uvpc) * uvslot
+            return (src_c[b].data_ptr(), out_c[b].data_ptr() if main else 0,
+                    [y_c[b // ypc].data_ptr() + (b % ypc) * yslot, u, u + vo])
+    else:
+        nbatch = max(1, min(want_frames // B, int(free * 0.8 // per_frame) // B))
+        src = torch.empty(nbatch * B * n3, dtype=torch.float32, device=dev)
+        out = torch.empty(nbatch * B * n3 if main else 0, dtype=torch.float32, device=dev)
+        planes = [torch.zeros(nbatch * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+
+        def ptrs(b):
+            return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4 if main else 0,
+                    [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
     nfr = nbatch * B
-    src = torch.empty(nfr * n3, dtype=torch.float32, device=dev)
-    out = torch.empty(nfr * n3 if main else 0, dtype=torch.float32, device=dev)
-    planes = [torch.zeros(nfr * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
     first = rank * nfr                                     # each rank has its own stream (weak scaling)
     for b in range(nbatch):
-        ctx.synth_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, SEED, first + b * B)
+        ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
     torch.cuda.synchronize()
-
-    def ptrs(b):
-        return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4 if main else 0,
-                [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
 
     def enc(i):
         s, _, pl = ptrs(i % nbatch)
@@ -278,8 +307,11 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             if main:
                 r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
     ctx.close()
-    del src, out, planes
-    torch.cuda.empty_cache()
+    if pool is not None:
+        pool.give_back(src_c + out_c + uv_c, y_c)
+    else:
+        del src, out, planes
+        torch.cuda.empty_cache()
     return r, cfg
 
 
@@ -414,6 +446,33 @@ def cpu_baseline(args, cfg, w, h):
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
 
+def make_pool(L, args, dev, local_rank, w, h, B):
+    """--placement auto: the chunk pool the resident streams are carved from (None: plain allocations)"""
+    if args.placement != "auto":
+        return None
+    try:
+        from lumahdrv_amd.placement import CHUNK_BYTES, HbmChunkPool, slots
+        n3 = 3 * w * h
+        _, hs, st, _ = L.plane_geometry(w, h, 2)
+        psz = [hs[p] * st[p] for p in range(3)]
+        ypc, _ = slots(CHUNK_BYTES, B * psz[0])
+        uvpc, _ = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
+            return None
+        nb = 500 // B                                      # the 500-frame stream: input + decoded output + U/V, and Y apart
+        n_other, n_y = 2 * nb + -(-nb // uvpc), -(-nb // ypc)
+        ctx = L.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
+        pool = HbmChunkPool(ctx, dev, n_other, n_y)
+        ctx.close()
+        return pool if pool.other and pool.y else None
+    except Exception as e:      # placement is an optimisation, never a reason to fail the bench
+        sys.stderr.write("bench.py: chunk pool unavailable (%r), plain allocations\n" % (e,))
+        torch.cuda.empty_cache()
+        return None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -453,7 +512,8 @@ def main():
         res = run_stream(L, args, rank, n_gpus, local_rank, use_dist, dev)
     else:
         w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
-        r, cfg = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, True, sha)
+        pool = make_pool(L, args, dev, local_rank, w, h, B)
+        r, cfg = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, True, sha, pool)
         res = {
             "metric": "Mpixels/s HDR quantize (4K PQ Lu'v' 11-bit)" if args.workload == "pq11_luv" and (w, h) == (W4K, H4K)
                       else "Mpixels/s HDR quantize (%s %dx%d)" % (args.workload, w, h),
@@ -472,6 +532,7 @@ def main():
             "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
             "decode_mpix_s": r["decode_mpix_s"], "roundtrip_mpix_s": r["roundtrip_mpix_s"],
             "kernel_source_sha": sha,
+            "placement": dict({"mode": args.placement}, **(pool.stats if pool is not None else {})),
         }
         if rank == 0:
             res["roofline"] = r["roofline"]
@@ -480,9 +541,11 @@ def main():
             others = {}
             for key, (nm, ow, oh, ob) in {"pq10_ycbcr_4k": ("pq10_ycbcr", W4K, H4K, 20),
                                            "log12_luv_8k": ("log12_luv", W8K, H8K, 5)}.items():
-                ro, _ = run_workload(L, args, nm, ow, oh, ob, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha)
+                ro, _ = run_workload(L, args, nm, ow, oh, ob, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha, pool)
                 others[key] = ro
             res["other_workloads"] = others
+        if pool is not None:
+            pool.close()
         if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cfg, w, h)
 

@@ -1,0 +1,60 @@
+"""lumahdrv_amd.placement.HbmChunkPool on a real MI355X: the pool builds, reports its groups, hands out chunks, and frames
+encoded into chunk-placed buffers give the bytes they give in plainly allocated buffers (placement never touches results)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
+    import torch
+    import lumahdrv_amd as L
+    from lumahdrv_amd.placement import CHUNK_BYTES, HbmChunkPool
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
+    pool = HbmChunkPool(ctx, dev, n_other=4, n_y=1)
+    st_ = pool.stats
+    assert st_["chunks"] >= 5 and len(pool.other) == 4 and len(pool.y) == 1
+    if st_["grouped"]:
+        assert sum(st_["groups"]) == st_["chunks"] and len(st_["groups"]) >= 2
+        pm = st_["probe_ms"]
+        # the point of the exercise: the chosen layout is not slower than input and planes sharing one group
+        assert pm["chosen_layout_y_apart"] <= pm["input_and_planes_in_one_group"] * 1.01
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_after > 100 * 2 ** 30        # everything that was not kept went back to the driver
+
+    w, h, B, profile = 1280, 720, 4, 2
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src_c, uv_c = pool.take_other(2)
+    y_c, = pool.take_y(1)
+    for c in (uv_c, y_c):
+        c.zero_()
+    ctx.synth_frames_device(src_c.data_ptr(), n3, B, w, h, 7, 0)
+    pl = [y_c.data_ptr(), uv_c.data_ptr(), uv_c.data_ptr() + (1 << 28)]
+    ctx.encode_frames_device(src_c.data_ptr(), n3, B, w, h, 1.0, profile, pl, st, psz)
+    # the same frames through plain tensors
+    src = torch.empty(B * n3, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.synth_frames_device(src.data_ptr(), n3, B, w, h, 7, 0)
+    ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, 1.0, profile, [p.data_ptr() for p in planes], st, psz)
+    torch.cuda.synchronize()
+    assert torch.equal(src_c[:B * n3 * 4].view(torch.float32), src)
+    assert torch.equal(y_c[:B * psz[0]], planes[0])
+    assert torch.equal(uv_c[:B * psz[1]], planes[1])
+    assert torch.equal(uv_c[(1 << 28):(1 << 28) + B * psz[2]], planes[2])
+    # and against the oracle for the first frame
+    o = oracle_mod
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    e, _, _ = orc.encode(o.synth_frame(w, h, 7, 0), 1.0, profile)
+    got_y = y_c[:psz[0]].cpu().numpy().reshape(hs[0], st[0])
+    assert np.array_equal(got_y, e[0])
+    pool.give_back([src_c, uv_c], [y_c])
+    pool.close()
+    ctx.set_stream(None)
+    ctx.close()
+    assert CHUNK_BYTES == 2 << 30
