@@ -202,13 +202,14 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             pool = None
     if pool is not None:
         # float frames: one chunk per batch of input, one per batch of decoded output; Y planes of `ypc` batches per chunk
-        # of the Y group; U and V planes of `uvpc` batches per chunk of the other groups (lumahdrv_amd/placement.py)
+        # of one group; U and V planes of `uvpc` batches per chunk of another (lumahdrv_amd/placement.py)
         nbatch = max(1, want_frames // B)
-        while nbatch > 1 and (nbatch * (2 if main else 1) + -(-nbatch // uvpc) > len(pool.other) or -(-nbatch // ypc) > len(pool.y)):
+        while nbatch > 1 and (nbatch * (2 if main else 1) > len(pool.float) or -(-nbatch // uvpc) > len(pool.uv)
+                              or -(-nbatch // ypc) > len(pool.y)):
             nbatch -= 1
-        src_c = pool.take_other(nbatch)
-        out_c = pool.take_other(nbatch) if main else []
-        uv_c = pool.take_other(-(-nbatch // uvpc))
+        src_c = pool.take_float(nbatch)                    # fastest first: the input gets the best chunks
+        out_c = pool.take_float(nbatch) if main else []
+        uv_c = pool.take_uv(-(-nbatch // uvpc))
         y_c = pool.take_y(-(-nbatch // ypc))
         for c in uv_c + y_c:
             c.zero_()
@@ -308,7 +309,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
     ctx.close()
     if pool is not None:
-        pool.give_back(src_c + out_c + uv_c, y_c)
+        pool.give_back(src_c + out_c, y_c, uv_c)
     else:
         del src, out, planes
         torch.cuda.empty_cache()
@@ -460,13 +461,13 @@ def make_pool(L, args, dev, local_rank, w, h, B):
         if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
             return None
         nb = 500 // B                                      # the 500-frame stream: input + decoded output + U/V, and Y apart
-        n_other, n_y = 2 * nb + -(-nb // uvpc), -(-nb // ypc)
+        n_float, n_y, n_uv = 2 * nb, -(-nb // ypc), -(-nb // uvpc)
         ctx = L.Context(local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
-        pool = HbmChunkPool(ctx, dev, n_other, n_y)
+        pool = HbmChunkPool(ctx, dev, n_float, n_y, n_uv)
         ctx.close()
-        return pool if pool.other and pool.y else None
+        return pool if pool.float and pool.y and pool.uv else None
     except Exception as e:      # placement is an optimisation, never a reason to fail the bench
         sys.stderr.write("bench.py: chunk pool unavailable (%r), plain allocations\n" % (e,))
         torch.cuda.empty_cache()

@@ -74,6 +74,7 @@ struct lumahip_ctx {
     bool block_forced = false;
     bool allow_alias = false;  // LUMAHIP_ALLOW_ALIASED_FRAMES=1: measurement tools alias all frames of a batch onto one
     int blocks_per_cu = 0;  // 0 = occupancy query
+    long grid_override[2] = {0, 0};
     size_t lds_table_max = LUMAHIP_LDS_TABLE_MAX_DEFAULT;
 };
 
@@ -146,6 +147,10 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
     }
     if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
         c->blocks_per_cu = atoi(e);
+    if (const char *e = getenv("LUMAHIP_GRID_ENC"))
+        c->grid_override[0] = atol(e);
+    if (const char *e = getenv("LUMAHIP_GRID_DEC"))
+        c->grid_override[1] = atol(e);
     if (const char *e = getenv("LUMAHIP_ALLOW_ALIASED_FRAMES"))
         c->allow_alias = atoi(e) != 0;
     if (const char *e = getenv("LUMAHIP_LDS_TABLE_MAX_KB")) {
@@ -444,10 +449,20 @@ static bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsi
 // Persistent workgroups, but deliberately MORE of them than fit at once (8 x 256 threads per CU requested, 5-6
 // resident at 80-96 VGPRs): the surplus is dispatched as resident ones retire, which evens out the tail; measured
 // 3-6 % faster than an occupancy-sized grid (tools/tune.py).  LUMAHIP_BLOCKS_PER_CU overrides for experiments.
-static int grid_for(const lumahip_ctx *c, int threads, int total_tiles)
+// Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute)
+// and LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
+static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false)
 {
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
+    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
+    // The 4:2:0 16-bit decode kernels write 12 of their 15 bytes per pixel, and fewer concurrent writers suit the memory
+    // system better: 5 workgroups of 256 threads per CU instead of 8 is 2.7-3.6 % faster on batched launches, both builds
+    // in one process (profiles/r02_grid_sweep.txt; the same change is 4 % SLOWER for 4:4:4 Lu'v' and 10 % slower for the
+    // 8-bit profiles, so it is theirs only).  Only where the launch is long enough for the coarser tail not to matter.
+    if (few_writers && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 12L * c->num_cu * 5)
+        per_cu = 5;
     long g = (long)c->num_cu * per_cu;
+    if (c->grid_override[dir] > 0)
+        g = c->grid_override[dir];
     if (g > total_tiles)
         g = total_tiles;
     if (g < 1)
@@ -554,7 +569,7 @@ static int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t fr
     enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0);
     if (stats)
         hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
@@ -632,7 +647,7 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
@@ -760,7 +775,7 @@ extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *
         a.stride[p] = stride[p];
         a.dst_frame_stride[p] = pfs[p];
     }
-    const int grid = grid_for(c, threads, a.g.totalTiles);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0);
     EventPair ev;
     HIPCHK(c, ev.create());
     HIPCHK(c, hipEventRecord(ev.e0, c->stream));

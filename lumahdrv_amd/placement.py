@@ -69,17 +69,6 @@ def find_groups(n, probe, max_groups=16):
     return groups, fast, probes
 
 
-def choose_roles(group_sizes, n_other, n_y):
-    """which group holds the Y planes: the smallest group that has n_y chunks while the OTHER groups together have n_other.
-    Returns the group index or None."""
-    total = sum(group_sizes)
-    best = None
-    for g, sz in enumerate(group_sizes):
-        if sz >= n_y and total - sz >= n_other and (best is None or sz < group_sizes[best]):
-            best = g
-    return best
-
-
 def slots(chunk_bytes, nbytes, align=64 << 20):
     """(how many buffers of nbytes fit one chunk, the slot size)"""
     slot = (nbytes + align - 1) // align * align
@@ -87,12 +76,17 @@ def slots(chunk_bytes, nbytes, align=64 << 20):
 
 
 class HbmChunkPool:
-    """Takes the free device memory of `dev` in chunks of CHUNK_BYTES (leaving `keep_free` bytes), finds the groups with the
-    traffic-only launch of `ctx` (lumahip_probe_encode_traffic_device: the loads and stores of the 4:2:0 encode kernel, no
-    arithmetic), keeps `n_y` chunks of one group for Y planes and `n_other` chunks of the other groups for everything else,
-    and returns the rest to the driver.  `ctx` needs a quantizer set; probing overwrites the chunks."""
+    """Takes the free device memory of `dev` in chunks of CHUNK_BYTES (leaving `keep_free` bytes) and chooses, by
+    measurement, `n_y` chunks for Y planes, `n_uv` chunks for U / V planes and `n_float` chunks for float frames; the rest
+    goes back to the driver.  Every measurement is the traffic-only launch of `ctx` (lumahip_probe_encode_traffic_device:
+    the loads and stores of the 4:2:0 encode kernel, no arithmetic); `ctx` needs a quantizer set, probing overwrites the
+    chunks.  Steps: (1) find the groups (find_groups); (2) Y candidates = the smallest group that is large enough, U / V
+    candidates = another group, reference float chunk = first chunk of the largest remaining group; (3) keep the Y and
+    U / V candidates that run fastest with the reference; (4) rank ALL remaining chunks as float chunks by their time
+    with the chosen planes chunks and keep the fastest -- so an imperfect grouping costs probes, not bandwidth."""
 
-    def __init__(self, ctx, dev, n_other, n_y, keep_free=6 << 30, iters=2):
+    def __init__(self, ctx, dev, n_float, n_y, n_uv, keep_free=6 << 30, iters=2):
+        import statistics
         import torch
         from . import capi
         self.dev = dev
@@ -104,9 +98,9 @@ class HbmChunkPool:
             except RuntimeError:        # out of memory: use what we have
                 break
         n = len(chunks)
-        self.stats = {"chunk_GiB": CHUNK_BYTES / 2 ** 30, "chunks": n, "y_chunks": n_y, "other_chunks": n_other}
-        self.other, self.y = [], []
-        if n < n_other + n_y or n < 3:
+        self.stats = {"chunk_GiB": CHUNK_BYTES / 2 ** 30, "chunks": n, "float_chunks": n_float, "y_chunks": n_y, "uv_chunks": n_uv}
+        self.float, self.y, self.uv = [], [], []
+        if n < n_float + n_y + n_uv or n < 4:
             self.stats["grouped"] = False
             self.stats["note"] = "not enough device memory for the chunk pool"
             chunks = None
@@ -118,58 +112,88 @@ class HbmChunkPool:
         psz = [hs[p] * st[p] for p in range(3)]
         _, _, offs = plane_slots(CHUNK_BYTES, [B * x for x in psz])
         assert B * n3 * 4 <= CHUNK_BYTES
+        nprobe = [0]
 
         def probe4(i, y, u, v):
-            pl = [y.data_ptr() + offs[0], u.data_ptr() + offs[1], v.data_ptr() + offs[2]]
-            return ctx.probe_encode_traffic(i.data_ptr(), n3, B, w, h, pl, st, psz, iters=iters)
+            nprobe[0] += 1
+            pl = [chunks[y].data_ptr() + offs[0], chunks[u].data_ptr() + offs[1], chunks[v].data_ptr() + offs[2]]
+            return ctx.probe_encode_traffic(chunks[i].data_ptr(), n3, B, w, h, pl, st, psz, iters=iters)
 
-        def probe(i, r):                                        # reads chunk i, writes all three planes into chunk r
-            return probe4(chunks[i], chunks[r], chunks[r], chunks[r])
-
-        probe(1, 0)                                              # warm-up (first touch of the code object)
-        groups, fast, probes = find_groups(n, probe)
-        torch.cuda.synchronize(dev)
-        self.stats["probes"] = probes
-        gy = choose_roles([len(g) for g in groups], n_other, n_y) if groups else None
+        probe4(1, 0, 0, 0)                                       # warm-up (first touch of the code object)
+        groups, fast, _ = find_groups(n, lambda i, r: probe4(i, r, r, r))
+        sizes = [len(g) for g in groups] if groups else None
+        self.stats["groups"] = sizes
+        gy = None
+        if groups and len(groups) >= 2:
+            order = sorted(range(len(groups)), key=lambda g: sizes[g])
+            fit = [g for g in order if sizes[g] >= n_y + 1]
+            gy = fit[0] if fit else None
         if gy is None:
-            # no contrast, or no group layout that fits: plain choice (the first chunks), reported as such
+            # no contrast or no usable group: plain choice (the first chunks), reported as such
             self.stats["grouped"] = False
-            self.stats["groups"] = [len(g) for g in groups] if groups else None
-            self.other, self.y = chunks[:n_other], chunks[n_other:n_other + n_y]
+            self.float = chunks[:n_float]
+            self.y = chunks[n_float:n_float + n_y]
+            self.uv = chunks[n_float + n_y:n_float + n_y + n_uv]
         else:
             self.stats["grouped"] = True
-            self.stats["groups"] = [len(g) for g in groups]
-            self.stats["y_group"] = gy
-            self.y = [chunks[i] for i in groups[gy][:n_y]]
-            rest = [i for g, grp in enumerate(groups) if g != gy for i in grp]
-            self.other = [chunks[i] for i in rest[:n_other]]
-            # the three layouts of the module docstring, measured on THIS box with the chunks just chosen
-            o0, o1 = self.other[0], self.other[-1]
-            same = [chunks[i] for i in groups[gy][:2]] if len(groups[gy]) >= 2 else None
+            rest_groups = [g for g in sorted(range(len(groups)), key=lambda g: -sizes[g]) if g != gy]
+            g_in = rest_groups[0]                                # the largest other group holds the reference float chunk
+            g_uv = rest_groups[-1] if sizes[rest_groups[-1]] >= n_uv + 1 else g_in
+            cref = groups[g_in][0]
+            ycand = groups[gy][:max(n_y + 6, 12)]
+            uvcand = [i for i in groups[g_uv] if i != cref][:max(n_uv + 5, 8)]
+            # (3) planes chunks that run fastest with the reference float chunk
+            ty = {k: probe4(cref, k, uvcand[0], uvcand[0]) for k in ycand}
+            ysel = sorted(ycand, key=lambda k: ty[k])[:n_y]
+            tu = {k: probe4(cref, ysel[0], k, k) for k in uvcand}
+            uvsel = sorted(uvcand, key=lambda k: tu[k])[:n_uv]
+            # (4) every other chunk as a float chunk against the chosen planes chunks
+            taken = set(ysel) | set(uvsel)
+            cand = [i for i in range(n) if i not in taken]
+            tf = {i: probe4(i, ysel[0], uvsel[0], uvsel[0]) for i in cand}
+            fsel = sorted(cand, key=lambda i: tf[i])[:n_float]
+            self.y = [chunks[i] for i in ysel]
+            self.uv = [chunks[i] for i in uvsel]
+            self.float = [chunks[i] for i in fsel]
+            same = groups[gy][:2]
+            tsel = [tf[i] for i in fsel]
+            self.stats["y_group"], self.stats["uv_group"] = gy, g_uv
             self.stats["probe_ms"] = {
-                "input_and_planes_in_one_group": round(probe4(same[0], same[1], same[1], same[1]), 4) if same else None,
+                "input_and_planes_in_one_group": round(probe4(same[0], same[1], same[1], same[1]), 4),
                 "planes_together_in_another_group": round(fast, 4),
-                "chosen_layout_y_apart": round(probe4(o0, self.y[0], o1, o1), 4)}
+                "float_chunks_kept_fastest": round(min(tsel), 4), "float_chunks_kept_median": round(statistics.median(tsel), 4),
+                "float_chunks_kept_slowest": round(max(tsel), 4),
+                "float_chunks_rejected_median": round(statistics.median([tf[i] for i in cand if i not in set(fsel)] or [0.0]), 4),
+                "y_chunks_kept_slowest": round(max(ty[k] for k in ysel), 4), "uv_chunks_kept_slowest": round(max(tu[k] for k in uvsel), 4)}
+        torch.cuda.synchronize(dev)
+        self.stats["probes"] = nprobe[0]
         chunks = None
         torch.cuda.empty_cache()
 
-    def take_other(self, n):
-        if n > len(self.other):
-            raise RuntimeError("HbmChunkPool: %d chunks wanted, %d left" % (n, len(self.other)))
-        got, self.other = self.other[:n], self.other[n:]
+    @staticmethod
+    def _take(lst, n, what):
+        if n > len(lst):
+            raise RuntimeError("HbmChunkPool: %d %s chunks wanted, %d left" % (n, what, len(lst)))
+        return lst[:n], lst[n:]
+
+    def take_float(self, n):
+        got, self.float = self._take(self.float, n, "float")
         return got
 
     def take_y(self, n):
-        if n > len(self.y):
-            raise RuntimeError("HbmChunkPool: %d Y chunks wanted, %d left" % (n, len(self.y)))
-        got, self.y = self.y[:n], self.y[n:]
+        got, self.y = self._take(self.y, n, "Y")
         return got
 
-    def give_back(self, other, y):
-        self.other = list(other) + self.other
+    def take_uv(self, n):
+        got, self.uv = self._take(self.uv, n, "U/V")
+        return got
+
+    def give_back(self, floats, y, uv):
+        self.float = list(floats) + self.float
         self.y = list(y) + self.y
+        self.uv = list(uv) + self.uv
 
     def close(self):
         import torch
-        self.other, self.y = [], []
+        self.float, self.y, self.uv = [], [], []
         torch.cuda.empty_cache()

@@ -15,14 +15,14 @@ def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
     ctx = L.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
-    pool = HbmChunkPool(ctx, dev, n_other=4, n_y=1)
+    pool = HbmChunkPool(ctx, dev, n_float=3, n_y=1, n_uv=1)
     st_ = pool.stats
-    assert st_["chunks"] >= 5 and len(pool.other) == 4 and len(pool.y) == 1
+    assert st_["chunks"] >= 5 and len(pool.float) == 3 and len(pool.y) == 1 and len(pool.uv) == 1
     if st_["grouped"]:
         assert sum(st_["groups"]) == st_["chunks"] and len(st_["groups"]) >= 2
         pm = st_["probe_ms"]
         # the point of the exercise: the chosen layout is not slower than input and planes sharing one group
-        assert pm["chosen_layout_y_apart"] <= pm["input_and_planes_in_one_group"] * 1.01
+        assert pm["float_chunks_kept_slowest"] <= pm["input_and_planes_in_one_group"] * 1.01
     free_after, _ = torch.cuda.mem_get_info(dev)
     assert free_after > 100 * 2 ** 30        # everything that was not kept went back to the driver
 
@@ -30,7 +30,8 @@ def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
     n3 = 3 * w * h
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
-    src_c, uv_c = pool.take_other(2)
+    src_c, = pool.take_float(1)
+    uv_c, = pool.take_uv(1)
     y_c, = pool.take_y(1)
     for c in (uv_c, y_c):
         c.zero_()
@@ -53,7 +54,7 @@ def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
     e, _, _ = orc.encode(o.synth_frame(w, h, 7, 0), 1.0, profile)
     got_y = y_c[:psz[0]].cpu().numpy().reshape(hs[0], st[0])
     assert np.array_equal(got_y, e[0])
-    pool.give_back([src_c, uv_c], [y_c])
+    pool.give_back([src_c], [y_c], [uv_c])
     pool.close()
     ctx.set_stream(None)
     ctx.close()

@@ -2,7 +2,7 @@
 synthetic timings -- CPU only; the pool itself is exercised on the GPU by tests/test_gpu_multi.py."""
 import random
 
-from lumahdrv_amd.placement import CHUNK_BYTES, choose_roles, find_groups, plane_slots, slots
+from lumahdrv_amd.placement import CHUNK_BYTES, find_groups, plane_slots, slots
 
 
 def _probe_for(group_of, fast=0.428, slow=0.457, noise=0.002, seed=1):
@@ -34,10 +34,7 @@ def test_find_groups_without_contrast_reports_none():
     assert groups == [[0]]
 
 
-def test_choose_roles_and_slots():
-    assert choose_roles([53, 48, 39], 53, 5) == 2          # smallest group that leaves enough for the rest
-    assert choose_roles([53, 48, 3], 53, 5) == 1
-    assert choose_roles([30, 4], 40, 5) is None
+def test_slots():
     # 4K, 20 frames per batch: Y 331.8 MB, U + V 165.9 MB
     ypc, yslot = slots(CHUNK_BYTES, 20 * 2160 * 7680)
     assert ypc == 6 and yslot % (64 << 20) == 0 and yslot >= 20 * 2160 * 7680
