@@ -352,18 +352,45 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     free, _total = torch.cuda.mem_get_info(dev)
     if (n3 * 4 + sum(psz)) * max(nfr, 1) > free * 0.9:
         raise SystemExit("rank %d: shard of %d frames does not fit in HBM" % (rank, nfr))
-    src = torch.empty(max(nfr, 1) * n3, dtype=torch.float32, device=dev)
-    planes = [torch.zeros(max(nfr, 1) * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
-    for f0 in range(0, nfr, B):
-        ctx.synth_frames_device(src.data_ptr() + f0 * n3 * 4, n3, min(B, nfr - f0), w, h, SEED, mine.start + f0)
     steps = (nfr + B - 1) // B
+    pool = None
+    shard_bytes = (n3 * 4 + sum(psz)) * nfr
+    if args.placement == "auto" and 8e9 <= shard_bytes <= free * 0.6:      # (a few GB: not worth probing 280 GB for)
+        pool = make_pool(L, args, dev, local_rank, w, h, B, nbatches=steps, with_output=False)
+    if pool is not None:
+        # step k's frames in chunk k of the pool's float chunks; Y and U / V planes in their own chunks (placement.py)
+        from lumahdrv_amd.placement import CHUNK_BYTES, slots
+        ypc, yslot = slots(CHUNK_BYTES, B * psz[0])
+        uvpc, uvslot = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        src_c, y_c, uv_c = pool.take_float(steps), pool.take_y(-(-steps // ypc)), pool.take_uv(-(-steps // uvpc))
+        vo = (B * psz[1] + (1 << 20) - 1) // (1 << 20) * (1 << 20)
+
+        def where(k):      # (input pointer, plane pointers) of step k
+            u = uv_c[k // uvpc].data_ptr() + (k % uvpc) * uvslot
+            return src_c[k].data_ptr(), [y_c[k // ypc].data_ptr() + (k % ypc) * yslot, u, u + vo]
+
+        def plane_views(k, nb):
+            yo, uo = (k % ypc) * yslot, (k % uvpc) * uvslot
+            return [y_c[k // ypc][yo:yo + nb * psz[0]], uv_c[k // uvpc][uo:uo + nb * psz[1]],
+                    uv_c[k // uvpc][uo + vo:uo + vo + nb * psz[2]]]
+    else:
+        src = torch.empty(max(nfr, 1) * n3, dtype=torch.float32, device=dev)
+        planes = [torch.zeros(max(nfr, 1) * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+
+        def where(k):
+            return src.data_ptr() + k * B * n3 * 4, [planes[p].data_ptr() + k * B * psz[p] for p in range(3)]
+
+        def plane_views(k, nb):
+            return [planes[p][k * B * psz[p]:(k * B + nb) * psz[p]] for p in range(3)]
+    for k in range(steps):
+        ctx.synth_frames_device(where(k)[0], n3, min(B, nfr - k * B), w, h, SEED, mine.start + k * B)
 
     def enc(i):
-        f0 = (i % max(steps, 1)) * B
-        nb = min(B, nfr - f0)
+        k = i % max(steps, 1)
+        nb = min(B, nfr - k * B)
         if nb > 0:
-            ctx.encode_frames_device(src.data_ptr() + f0 * n3 * 4, n3, nb, w, h, sc, profile,
-                                     [planes[p].data_ptr() + f0 * psz[p] for p in range(3)], st, psz)
+            s_, pl_ = where(k)
+            ctx.encode_frames_device(s_, n3, nb, w, h, sc, profile, pl_, st, psz)
 
     ksteps = torch.tensor([steps], dtype=torch.int64, device=dev)
     if use_dist:
@@ -375,7 +402,10 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     torch.cuda.synchronize()
     # in-order reassembly bookkeeping: per-frame digests gathered in STREAM order; rank 0 re-encodes the first and last
     # frame of every shard itself and compares
-    dig = frame_digests(planes, psz, nfr, dev).cpu().tolist() if nfr else []
+    dig = []
+    for k in range(steps):
+        nb = min(B, nfr - k * B)
+        dig += frame_digests(plane_views(k, nb), psz, nb, dev).cpu().tolist()
     allv = gather_in_stream_order(dig, F, dev)
     checked = 0
     if rank == 0:
@@ -403,8 +433,12 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
            "repeats": te["repeats"], "timed_seconds": round(te["seconds"], 3),
            "ms_per_region_min_median_max": [round(1e3 * te[k], 3) for k in ("wall_min", "wall_median", "wall_max")],
            "digests": {"gathered_in_stream_order": len(allv), "spot_checked_by_rank0": checked,
-                       "stream_digest": "%016x" % (sum((i + 1) * v for i, v in enumerate(allv)) & 0xFFFFFFFFFFFFFFFF)}}
+                       "stream_digest": "%016x" % (sum((i + 1) * v for i, v in enumerate(allv)) & 0xFFFFFFFFFFFFFFFF)},
+           "placement": dict({"mode": args.placement if pool is not None else "off (plain allocations)"},
+                             **(pool.stats if pool is not None else {}))}
     ctx.close()
+    if pool is not None:
+        pool.close()
     return res
 
 
@@ -447,7 +481,7 @@ def cpu_baseline(args, cfg, w, h):
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
 
-def make_pool(L, args, dev, local_rank, w, h, B):
+def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True):
     """--placement auto: the chunk pool the resident streams are carved from (None: plain allocations)"""
     if args.placement != "auto":
         return None
@@ -460,8 +494,8 @@ def make_pool(L, args, dev, local_rank, w, h, B):
         uvpc, _ = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
         if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
             return None
-        nb = 500 // B                                      # the 500-frame stream: input + decoded output + U/V, and Y apart
-        n_float, n_y, n_uv = 2 * nb, -(-nb // ypc), -(-nb // uvpc)
+        nb = nbatches if nbatches else 500 // B            # default: the 500-frame stream, input + decoded output
+        n_float, n_y, n_uv = (2 if with_output else 1) * nb, -(-nb // ypc), -(-nb // uvpc)
         ctx = L.Context(local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
