@@ -460,6 +460,13 @@ static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir,
     // 8-bit profiles, so it is theirs only).  Only where the launch is long enough for the coarser tail not to matter.
     if (few_writers && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 12L * c->num_cu * 5)
         per_cu = 5;
+    // The encode kernels with 256-thread workgroups (tables up to 32 KiB; not YCbCr, which is VALU-bound and wants the
+    // waves) run 3-6 % faster on long launches with 3 workgroups per CU than with 8 -- every colour space / profile
+    // variant, same build in one process (tools/ab_encode_grid.sh, profiles/r02_grid_sweep.txt); 6 per CU is 9 % SLOWER,
+    // 4 about as good as 3.  Fewer resident waves draw less power at the package limit and keep fewer streams open in the
+    // memory system.  Short launches keep 8 per CU for their tail.
+    if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 40L * c->num_cu * 3)
+        per_cu = 3;
     long g = (long)c->num_cu * per_cu;
     if (c->grid_override[dir] > 0)
         g = c->grid_override[dir];

@@ -49,8 +49,13 @@ def main():
     src = torch.empty(nb * B * n3, dtype=torch.float32, device=dev)
     planes = [torch.zeros(nb * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
     ctxs = []
-    for m in mods:
+    for side, m in zip("AB", mods):
+        # AB_ENV_A / AB_ENV_B = "NAME=value,NAME=value": environment switches read when that side's context is created
+        extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + side, "").split(",") if "=" in kv)
+        os.environ.update(extra)
         c = m.Context(0)
+        for k in extra:
+            os.environ.pop(k, None)
         c.set_quantizer(ptf, bits, cs, bitsC, mx, mn, m.build_lut(ptf, bits, mx, mn))
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         ctxs.append(c)
