@@ -338,10 +338,15 @@ static size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
 // Workgroup size of the fused kernels: 256 threads unless LUMAHIP_BLOCK says otherwise; search tables beyond
 // 32 KiB per workgroup would leave too few waves per CU at that size (160 KiB of LDS per CU), so the workgroup
 // grows with the table.
-static int block_threads_for(const lumahip_ctx *c, size_t lds)
+//   - `few_waves` (the encode kernels of the HBM-bound colour spaces on long launches, see grid_for): three 256-thread
+//     workgroups per CU are the fastest configuration measured, so the workgroup stays at 256 threads as long as three
+//     copies of the table fit the CU's LDS (LOG-12's 42 KiB of records: 3.9 % faster than four 512-thread workgroups).
+static int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false)
 {
     if (c->block_forced)
         return c->block_threads;
+    if (few_waves && c->block_threads == 256 && 3 * lds <= LUMAHIP_LDS_PER_WORKGROUP)
+        return 256;
     if (lds > 53 * 1024)
         return 1024;
     if (lds > 32 * 1024)
@@ -451,7 +456,7 @@ static bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsi
 // 3-6 % faster than an occupancy-sized grid (tools/tune.py).  LUMAHIP_BLOCKS_PER_CU overrides for experiments.
 // Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute)
 // and LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
-static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false)
+static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false)
 {
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
     // The 4:2:0 16-bit decode kernels write 12 of their 15 bytes per pixel, and fewer concurrent writers suit the memory
@@ -467,6 +472,11 @@ static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir,
     // memory system.  Short launches keep 8 per CU for their tail.
     if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 40L * c->num_cu * 3)
         per_cu = 3;
+    // The YCbCr kernels are VALU-bound and only three of their 512-thread workgroups (49 KiB of LDS each) are resident
+    // per CU: many more, smaller static shares balance the CUs better than one share per resident workgroup -- 18 per CU
+    // is 4.9 % faster than 4 for encode, 12 per CU 4.3 % for decode (same build in one process, profiles/r02_grid_sweep.txt).
+    if (ycbcr && c->blocks_per_cu == 0 && threads == 512 && total_tiles >= 8L * c->num_cu * 18)
+        per_cu = dir == 0 ? 18 : 12;
     long g = (long)c->num_cu * per_cu;
     if (c->grid_override[dir] > 0)
         g = c->grid_override[dir];
@@ -553,7 +563,8 @@ static int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t fr
     EncArgs a{};
     a.q = c->q;
     const size_t lds = lds_bytes(c, true, cs_eff);
-    const int threads = block_threads_for(c, lds);
+    const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
+    const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     a.src = rgb;
@@ -576,7 +587,7 @@ static int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t fr
     enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles, 0);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
     if (stats)
         hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
@@ -654,7 +665,7 @@ static int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], con
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr, cs_eff == CS_YCBCR);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
