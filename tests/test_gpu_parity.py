@@ -761,3 +761,40 @@ def test_random_monotone_tables_through_the_encode_kernel(L, oracle_mod):
         for p in range(3):
             assert np.array_equal(planes[p], exp[p]), (trial, p)
     assert 0 in modes and (3 in modes or 4 in modes)
+
+
+@pytest.mark.parametrize("name,nframes", [("pq11_luv8", 8), ("log12_luv8", 8), ("pq10_ycbcr10", 20)])
+def test_long_batched_launches_are_bit_exact(L, oracle_mod, name, nframes):
+    """Batched launches long enough for the launch-geometry rules of lumahip_capi.hip: grid_for / block_threads_for (3
+    workgroups per CU for the 256-thread encode kernels, 256-thread workgroups for LOG-12, 5 per CU for the 4:2:0 16-bit
+    decode kernels, 18 / 12 static shares per CU for YCbCr) -- every frame of the batch against the oracle, planes and
+    decoded floats, bit for bit."""
+    import torch
+    o = oracle_mod
+    cfg = CONFIGS[name]
+    q, orc = pair(L, o, cfg)
+    w, h, profile = 3840, 2160, 2
+    sc = 20.0 if cfg[2] == o.CS_YCBCR else 1.0
+    n3 = 3 * w * h
+    dev = torch.device("cuda:0")
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(nframes * n3, dtype=torch.float32, device=dev)
+    out = torch.empty(nframes * n3, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(nframes * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    q.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    q.ctx.synth_frames_device(src.data_ptr(), n3, nframes, w, h, 4242, 0)
+    pl = [p.data_ptr() for p in planes]
+    q.ctx.encode_frames_device(src.data_ptr(), n3, nframes, w, h, sc, profile, pl, st, psz)
+    q.ctx.decode_frames_device(pl, st, psz, nframes, w, h, profile, sc, out.data_ptr(), n3)
+    torch.cuda.synchronize()
+    q.ctx.set_stream(None)
+    nt = os.cpu_count() or 1
+    for f in range(nframes):
+        frame = o.synth_frame(w, h, 4242, f)
+        e, est, _ = orc.encode(frame.copy(), sc, profile, threads=nt)
+        for p in range(3):
+            got = planes[p][f * psz[p]:(f + 1) * psz[p]].cpu().numpy().reshape(hs[p], st[p])
+            assert np.array_equal(got, e[p]), (name, f, p)
+        exp = orc.decode(e, est, w, h, sc, profile, threads=nt)
+        assert same_bits(out[f * n3:(f + 1) * n3].cpu().numpy().reshape(3, h, w), exp), (name, f)
