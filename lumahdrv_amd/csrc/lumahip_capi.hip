@@ -451,11 +451,11 @@ static bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsi
     return true;
 }
 
-// Persistent workgroups, but deliberately MORE of them than fit at once (8 x 256 threads per CU requested, 5-6
-// resident at 80-96 VGPRs): the surplus is dispatched as resident ones retire, which evens out the tail; measured
-// 3-6 % faster than an occupancy-sized grid (tools/tune.py).  LUMAHIP_BLOCKS_PER_CU overrides for experiments.
-// Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute)
-// and LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
+// Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  The default is 2048 threads' worth per CU (8
+// workgroups of 256), i.e. MORE than are resident at once for most kernels: the surplus is dispatched as resident ones
+// retire, which evens out the tail of short launches.  The rules below are for long (batched) launches, each one found by
+// running both settings in one process (tools/ab_inproc.py).  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute) and
+// LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
 static int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false)
 {
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
