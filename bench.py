@@ -22,7 +22,7 @@ plane digests all_gathered in stream order and spot-checked by rank 0.
 
 Extra fields in the same line (not part of `value`): decode and encode+decode round trip, the roofline of the encode
 kernel (HIP events on the launch stream, live), `other_workloads` (BASELINE configs[2] HDR10/YCbCr at 4K and configs[3]
-LOG-12 at 7680x4320, each with its own roofline block; N = 1 only) and the CPU reference timed on this host
+LOG-12 at 7680x4320, each with its own roofline block and its decode rate; N = 1 only) and the CPU reference timed on this host
 (`cpu_baseline`, N = 1 only).
 """
 import argparse
@@ -191,7 +191,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
     n3 = 3 * w * h
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
-    per_frame = n3 * 4 * (2 if main else 1) + sum(psz)     # input (+ decoded output) + planes
+    per_frame = n3 * 4 * 2 + sum(psz)                      # input + decoded output + planes
     free, _total = torch.cuda.mem_get_info(dev)
     want_frames = 500 if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)    # >= 4 GB of distinct input: >> 256 MB MALL
     if pool is not None:
@@ -204,11 +204,11 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
         # float frames: one chunk per batch of input, one per batch of decoded output; Y planes of `ypc` batches per chunk
         # of one group; U and V planes of `uvpc` batches per chunk of another (lumahdrv_amd/placement.py)
         nbatch = max(1, want_frames // B)
-        while nbatch > 1 and (nbatch * (2 if main else 1) > len(pool.float) or -(-nbatch // uvpc) > len(pool.uv)
+        while nbatch > 1 and (nbatch * 2 > len(pool.float) or -(-nbatch // uvpc) > len(pool.uv)
                               or -(-nbatch // ypc) > len(pool.y)):
             nbatch -= 1
         src_c = pool.take_float(nbatch)                    # fastest first: the input gets the best chunks
-        out_c = pool.take_float(nbatch) if main else []
+        out_c = pool.take_float(nbatch)
         uv_c = pool.take_uv(-(-nbatch // uvpc))
         y_c = pool.take_y(-(-nbatch // ypc))
         for c in uv_c + y_c:
@@ -217,16 +217,15 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
 
         def ptrs(b):
             u = uv_c[b // uvpc].data_ptr() + (b % uvpc) * uvslot
-            return (src_c[b].data_ptr(), out_c[b].data_ptr() if main else 0,
-                    [y_c[b // ypc].data_ptr() + (b % ypc) * yslot, u, u + vo])
+            return (src_c[b].data_ptr(), out_c[b].data_ptr(), [y_c[b // ypc].data_ptr() + (b % ypc) * yslot, u, u + vo])
     else:
         nbatch = max(1, min(want_frames // B, int(free * 0.8 // per_frame) // B))
         src = torch.empty(nbatch * B * n3, dtype=torch.float32, device=dev)
-        out = torch.empty(nbatch * B * n3 if main else 0, dtype=torch.float32, device=dev)
+        out = torch.empty(nbatch * B * n3, dtype=torch.float32, device=dev)
         planes = [torch.zeros(nbatch * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
 
         def ptrs(b):
-            return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4 if main else 0,
+            return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4,
                     [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
     nfr = nbatch * B
     first = rank * nfr                                     # each rank has its own stream (weak scaling)
@@ -256,10 +255,10 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                      % (w, h, desc, xf_desc, B, nfr),
          "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
          "distinct_input_GB_per_gpu": round(nfr * n3 * 4 / 1e9, 2)}
+    td = tm.run(dec)                                       # (the planes every batch holds are the encode leg's)
+    r["decode_mpix_s"] = round(rate(td["wall_median"]), 1)
     if main:
-        td = tm.run(dec)
         trt = tm.run(lambda i: (enc(i), dec(i)))
-        r["decode_mpix_s"] = round(rate(td["wall_median"]), 1)
         r["roundtrip_mpix_s"] = round(rate(trt["wall_median"]), 1)
 
     if rank == 0:
@@ -305,8 +304,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                                       "hbm": hbm}, **common)
         else:
             r["roofline"] = dict(dict({"bound": "hbm"}, **hbm), **common)
-            if main:
-                r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
+            r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
     ctx.close()
     if pool is not None:
         pool.give_back(src_c + out_c, y_c, uv_c)
