@@ -80,6 +80,26 @@ def main():
         rows.append((name, t4(a, y, u, v, fs=fs), t4(a, y, u, v, True, fs=fs)))
     for name, p, e in rows:
         print("%-44s probe %.4f ms   encode %.4f ms" % (name, p, e), flush=True)
+    # a second layout: R and B planes in one group, G in another, all coded planes in the third
+    lib.lumahip_exp_set_chan_stride(0)
+    aba = None
+    for k in range(1, n // 2):
+        for i in range(n - 2 * k):
+            x, y, z = i + 2 * k, i + k, i
+            if va[y] - va[x] == va[z] - va[y] and gid[x] == gid[z] != gid[y] and not ({x, y, z} & {a, b, c}):
+                aba = (x, y, z)
+                break
+        if aba:
+            break
+    if aba:
+        x, y, z = aba
+        third = [g for g in range(len(groups)) if g not in (gid[x], gid[y])]
+        if third:
+            pc = [i for i in range(n) if gid[i] == third[0] and i not in (x, y, z, a, b, c)]
+            lib.lumahip_exp_set_chan_stride((va[y] - va[x]) // 4)
+            print("%-44s probe %.4f ms   encode %.4f ms" % ("R, B in A, G in B; Y U V in C (one chunk)", t4(x, pc[0], pc[0], pc[0], fs=fs), t4(x, pc[0], pc[0], pc[0], True, fs=fs)))
+            print("%-44s probe %.4f ms   encode %.4f ms" % ("R, B in A, G in B; Y in C, U V in C'", t4(x, pc[0], pc[1], pc[1], fs=fs), t4(x, pc[0], pc[1], pc[1], True, fs=fs)))
+            lib.lumahip_exp_set_chan_stride(0)
     # decode: planes read, floats written
     pl = [chunks[ya].data_ptr() + offs[0], chunks[ub].data_ptr() + offs[1], chunks[uc].data_ptr() + offs[2]]
     ctx.encode_frames_device(va[a], fs, B, w, h, 1.0, profile, pl, st, psz)
