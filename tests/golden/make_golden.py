@@ -46,6 +46,26 @@ def special_frame(h=8, w=16, seed=7):
     return f
 
 
+def extreme_frame(h=4, w=32):
+    """(3,h,w) float32 of inputs at the edges of fp32: inf - inf patterns inside the RGB -> XYZ rows, +-FLT_MAX (partial sums
+    that overflow), NaNs of both signs in every position, -0, denormals.  Not a stored fixture: both sides of a comparison
+    evaluate it (oracle against the live reference on CPU, HIP against the oracle on the GPU)."""
+    M = np.finfo(np.float32).max
+    nan_neg = np.array([0xffc00000], dtype=np.uint32).view(np.float32)[0]
+    tiny = np.float32(1e-45)
+    px = [(np.inf, -np.inf, 1), (np.inf, 1, -np.inf), (1, np.inf, -np.inf), (-np.inf, np.inf, np.inf), (np.inf, np.inf, np.inf),
+          (-np.inf, -np.inf, -np.inf), (M, M, M), (-M, M, M), (M, -M, M), (M, M, -M), (-M, -M, -M), (M, 0, 0), (0, M, 0), (0, 0, M),
+          (np.nan, np.nan, np.nan), (1, np.nan, 1), (1, 1, np.nan), (nan_neg, 1, 1), (1, nan_neg, 1), (1, 1, nan_neg),
+          (-0.0, -0.0, -0.0), (-0.0, 1, 1), (tiny, tiny, tiny), (tiny, 1, 1), (1e-38, 1e-38, 1e-38), (1e38, 1e-38, 1),
+          (3.4e38, 1e-4, 1e-4), (1e-4, 3.4e38, 1e-4), (1e-4, 1e-4, 3.4e38), (-1e-45, 2, 2), (5e4, 5e4, 5e4), (0, 0, 0)]
+    f = np.ones((3, h, w), dtype=np.float32)
+    for i, p in enumerate(px[:w]):
+        f[:, 0, i] = np.array(p, dtype=np.float32)
+        f[:, 2, i] = np.array(p, dtype=np.float32)       # a second copy on another quad row (different averaging partners)
+    f[:, 3, :] = np.float32(0.25)
+    return f
+
+
 def main():
     o.build(ref=True)
     assert o.have_ref()

@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from tests.golden.make_golden import CONFIGS, special_frame  # noqa: E402
+from tests.golden.make_golden import CONFIGS, extreme_frame, special_frame  # noqa: E402
 
 
 def same_bits(a, b):
@@ -798,3 +798,27 @@ def test_long_batched_launches_are_bit_exact(L, oracle_mod, name, nframes):
             assert np.array_equal(got, e[p]), (name, f, p)
         exp = orc.decode(e, est, w, h, sc, profile, threads=nt)
         assert same_bits(out[f * n3:(f + 1) * n3].cpu().numpy().reshape(3, h, w), exp), (name, f)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_extreme_inputs_bit_exact(L, oracle_mod, name):
+    """inf - inf patterns inside the RGB -> XYZ rows, +-FLT_MAX, NaNs of both signs in every position, -0, denormals
+    (tests/golden/make_golden.py: extreme_frame; the oracle is pinned on exactly this frame against the live reference by
+    tests/test_oracle_golden.py): planes of every profile and the forward transform, bit for bit.  This is the frame that
+    would expose a clamp that treats NaN or infinity differently from std::max(std::min(v, 1e8f), 1e-4f)."""
+    o = oracle_mod
+    cfg = CONFIGS[name]
+    q, orc = pair(L, o, cfg)
+    f = extreme_frame()
+    for sc in (1.0, 20.0):
+        a, b = f.copy(), f.copy()
+        assert q.transformColorSpace(a, True, sc)
+        with np.errstate(all="ignore"):
+            orc.transform(b, True, sc)
+        assert same_bits(a, b), (name, sc)
+        for profile in (0, 1, 2, 3):
+            planes, st, _ = q.ctx.encode_frame(f.copy(), sc, profile)
+            with np.errstate(all="ignore"):
+                e, _, _ = orc.encode(f.copy(), sc, profile)
+            for p in range(3):
+                assert np.array_equal(planes[p], e[p]), (name, sc, profile, p)

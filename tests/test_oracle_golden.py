@@ -95,6 +95,29 @@ def test_live_reference_random_frames(oracle_mod):
             assert same(a2, b2), (name, sc, "inv")
 
 
+def test_live_reference_extreme_inputs(oracle_mod):
+    """inf - inf patterns, +-FLT_MAX, NaNs of both signs in every position, -0, denormals: the oracle's forward transform
+    and whole-frame encode against the REAL LumaQuantizer, every configuration, preScaling 1 and 20"""
+    from tests.golden.make_golden import extreme_frame
+    o = oracle_mod
+    if not o.have_ref():
+        pytest.skip("oracle/_ref/libluma_ref.so not built (needs /root/reference)")
+    f = extreme_frame()
+    for name, cfg in CONFIGS.items():
+        qq = o.Oracle(*cfg, table=table_for(o, cfg))
+        r = o.RefQuantizer(*cfg)
+        for sc in (1.0, 20.0):
+            a, b = f.copy(), f.copy()
+            with np.errstate(all="ignore"):
+                qq.transform(a, True, sc)
+                r.transform(b, True, sc)
+            assert same(a, b), (name, sc)
+            for profile in (2, 3):
+                pa, _, _ = qq.encode(f.copy(), sc, profile)
+                pb, _, _ = r.encode(f.copy(), sc, profile)
+                assert all(np.array_equal(x, y) for x, y in zip(pa, pb)), (name, sc, profile)
+
+
 def test_roundtrip_decode_of_encode(oracle_mod):
     """encode -> decode through the plane layout reproduces the dequantized Lu'v' of every pixel"""
     o = oracle_mod
