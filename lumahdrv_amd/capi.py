@@ -45,7 +45,7 @@ def build_library(force: bool = False, nofastdiv: bool = False) -> str:
     """Compile every HIP source for gfx950 into lumahdrv_amd/lib/liblumahip.so (hipcc cross-compiles
     without a GPU).  nofastdiv: additionally the -DLH_NO_FAST_DIV comparison build of the C ABI library
     (lumahdrv_amd/lib_nofastdiv/liblumahip.so) that tests/test_gpu_parity.py loads through LUMAHIP_LIB."""
-    cmd = ["make", "-s", "-C", os.path.join(HERE, "csrc")]
+    cmd = ["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(HERE, "csrc")]
     if force:
         subprocess.run(cmd + ["clean"], check=True)
     subprocess.run(cmd, check=True)
@@ -55,12 +55,16 @@ def build_library(force: bool = False, nofastdiv: bool = False) -> str:
     return os.path.join(HERE, "lib", "liblumahip.so")
 
 
+KERNEL_SOURCES = ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_internal.hpp", "lumahip_core.hip",
+                  "lumahip_encode.hip", "lumahip_decode.hip", "lumahip_misc.hip", "lut_index.cpp", "Makefile")
+
+
 def kernel_source_sha() -> str:
     """short SHA-1 over the device sources; profiles/*.json captured by rocprofv3 carry it so that bench.py never
     reports a counter-derived figure measured on different kernels"""
     import hashlib
     hsh = hashlib.sha1()
-    for f in ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_capi.hip", "lut_index.cpp", "Makefile"):
+    for f in KERNEL_SOURCES:
         with open(os.path.join(HERE, "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:12]

@@ -501,39 +501,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         stats_flush(st, a.stats, tx);
 }
 
-// Traffic probe: the loads and stores of k_encode<.,4:2:0,VW=4> for 16-bit planes with NO arithmetic (an xor
-// keeps every loaded word live).  Its run time is what the memory system alone needs for the encode traffic mix
-// (12 B read + 3 B written per pixel, same tile order, same non-temporal accesses); bench.py reports the encode
-// kernel's time as a fraction of it next to the fraction of the 8 TB/s peak.
-__global__ __launch_bounds__(256) void k_encode_traffic_probe(const EncArgs a)
-{
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int NW = blockDim.x >> 6;
-    const size_t cs = (size_t)a.g.w * a.g.h;
-    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
-        int f, bx, by;
-        tile_coords(t, a.g, f, bx, by);
-        const int ux = bx * 64 + tx, uy = by * NW + ty;
-        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
-            continue;
-        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * 4;
-        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                float v[4];
-                load_px<4>(p + c * cs + (size_t)r * a.g.w, v);
-                q0 ^= __float_as_uint(v[0]); q1 ^= __float_as_uint(v[1]); q2 ^= __float_as_uint(v[2]); q3 ^= __float_as_uint(v[3]);
-            }
-        unsigned char *d0 = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * 8;
-        nt_store_u32x2(d0, q0, q1);
-        nt_store_u32x2(d0 + a.stride[0], q2, q3);
-        nt_store_u32(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * 4, q0 ^ q2);
-        nt_store_u32(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * 4, q1 ^ q3);
-    }
-}
-
 // ---- DECODE ---------------------------------------------------------------------------------------
 // GL: LUT read from global memory (bitdepth > 12) instead of LDS.  Same software pipeline as encode: the
 // sample loads of the next unit are issued one iteration ahead, after the current unit's stores.
@@ -821,62 +788,6 @@ __global__ __launch_bounds__(256) void k_channel0(const float *src, size_t chan_
     }
 }
 
-__global__ __launch_bounds__(64) void k_seq_sum(const float *x, size_t n, float *out)
-{
-    const int lane = threadIdx.x;
-    float acc = 0.0f;
-    for (size_t base = 0; base < n; base += 64 * 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const size_t idx = base + (size_t)j * 64 + lane;
-            v[j] = idx < n ? x[idx] : 0.0f;  // acc + 0.0f == acc
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int i = 0; i < 64; i++)
-                acc = acc + __shfl(v[j], i, 64);
-    }
-    if (lane == 0)
-        out[0] = acc;
-}
-
-// ---- array quantize / dequantize (LumaQuantizer::quantize / dequantize over arrays) ----------------
-struct QArrArgs {
-    QuantDev q;
-    const float *in;
-    float *out;
-    size_t n;
-    int lut_channel;  // 1: LUT path, 0: colour path
-};
-
-// MODE: the table's search mode (lut_index.hpp LutMode), a template parameter so that each instantiation stages
-// exactly what it probes
-template <int MODE>
-__global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    stage_tables<(MODE == 0 ? STAGE_LUT : 0) | (MODE == 3 ? STAGE_REC : 0)>(smem, a.q);
-    const float *s_lut = reinterpret_cast<const float *>(smem);
-    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v[1] = {a.in[i]};
-        int c[1];
-        if (!a.lut_channel)
-            c[0] = quantize_color(v[0], a.q.maxC);
-        else if constexpr (MODE == 3)
-            quantize_lut<3, 1>(v, c, s_lut, s_rec, a.q);     // any NaN sign
-        else if constexpr (MODE == 4)
-            quantize_lut<4, 1>(v, c, a.q.lut, a.q.rec, a.q);
-        else if constexpr (MODE == 0)
-            quantize_lut<0, 1>(v, c, s_lut, s_rec, a.q);
-        else
-            quantize_lut<2, 1>(v, c, a.q.lut, s_rec, a.q);
-        a.out[i] = (float)c[0];
-    }
-}
-
 // Test probe: quantize_lut<LM, 4, NONNEG> -- the instantiation the Lu'v' encode kernels call for a row of four
 // luminances -- over consecutive fp32 bit patterns (tests/test_gpu_exhaustive.py; NONNEG promises v >= 0 or NaN, so
 // that sweep covers 0 .. 0x7fffffff plus the sign-set NaNs 0xff800001 .. 0xffffffff).
@@ -905,67 +816,5 @@ __global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16
     }
 }
 
-__global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
-{
-    // src/luma_quantizer.cpp:247-264 with a float argument (may be negative, fractional or NaN)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
-        const float val = a.in[i];
-        float res;
-        if (a.lut_channel) {
-            if (val < 0)
-                res = a.q.lut[0];
-            else if (val >= (float)a.q.maxVal)
-                res = a.q.lut[a.q.maxVal];
-            else
-                res = a.q.lut[(val != val) ? a.q.maxVal : (int)val];
-        } else {
-            res = std_max(div_ieee(val, a.q.maxC), 1e-10f);
-        }
-        a.out[i] = res;
-    }
-}
-
-// ---- powf probe: out[i] = powf_glibc(bits-to-float(first + i), y) (tests: device powf == host libm, exhaustively)
-__global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_bits, size_t n, float y, int regular)
-{
-    __shared__ PowfTablesWide s_pw;
-    stage_powf_tables(&s_pw);
-    __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = __uint_as_float(first_bits + (uint32_t)i);
-        float r;
-        if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
-            bool slow = false;
-            r = powf_regular<true, true, true>(x, y, s_pw, slow);
-            if (slow)
-                r = powf_glibc(x, y, s_pw);
-        } else {
-            r = powf_glibc(x, y, s_pw);
-        }
-        out[i] = r;
-    }
-}
-
-// ---- synthetic frames --------------------------------------------------------------
-LH_DEV uint64_t splitmix64(uint64_t x)
-{
-    uint64_t z = x + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__global__ __launch_bounds__(256) void k_synth(float *dst, size_t frame_stride, int nframes, size_t n3, uint64_t seed,
-                                                uint64_t first_frame)
-{
-    const size_t total = n3 * nframes;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = i / n3, j = i - f * n3;  // j = ch*h*w + idx
-        const uint64_t h64 = splitmix64(seed ^ ((first_frame + f) * 0x9E3779B97F4A7C15ull) ^ (uint64_t)j);
-        const uint32_t e = 117u + (uint32_t)((h64 >> 40) % 24u);
-        const uint32_t bits = (e << 23) + (uint32_t)(h64 & 0x7FE000u);
-        dst[f * frame_stride + j] = __uint_as_float(bits);
-    }
-}
 
 }  // namespace lh

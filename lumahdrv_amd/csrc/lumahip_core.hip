@@ -1,0 +1,446 @@
+// lumahip_core.hip -- context life cycle, quantizer upload, launch-geometry rules, memory helpers of include/lumahip.h.
+// No kernels here; the arithmetic is in luma_device.hpp / luma_kernels.hpp.
+#include "lumahip_internal.hpp"
+
+using namespace lh;
+using namespace lhost;
+
+int lumahip_fail(lumahip_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+extern "C" int lumahip_abi_version(void) { return LUMAHIP_ABI_VERSION; }
+
+extern "C" int lumahip_device_count(int *count)
+{
+    if (!count)
+        return LUMAHIP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return LUMAHIP_ERR_HIP;
+    }
+    *count = n;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_create(lumahip_ctx **out, int device)
+{
+    if (!out)
+        return LUMAHIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return LUMAHIP_ERR_HIP;  // no CPU fallback: the path needs a HIP device
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess)
+            return LUMAHIP_ERR_HIP;
+    }
+    if (device >= n)
+        return LUMAHIP_ERR_ARG;
+    lumahip_ctx *c = new lumahip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return LUMAHIP_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        c->num_cu = prop.multiProcessorCount;
+    if (const char *e = getenv("LUMAHIP_BLOCK")) {
+        int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
+            c->block_threads = v;
+            c->block_forced = true;
+        }
+    }
+    if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
+        c->blocks_per_cu = atoi(e);
+    if (const char *e = getenv("LUMAHIP_GRID_ENC"))
+        c->grid_override[0] = atol(e);
+    if (const char *e = getenv("LUMAHIP_GRID_DEC"))
+        c->grid_override[1] = atol(e);
+    if (const char *e = getenv("LUMAHIP_ALLOW_ALIASED_FRAMES"))
+        c->allow_alias = atoi(e) != 0;
+    if (const char *e = getenv("LUMAHIP_LDS_TABLE_MAX_KB")) {
+        const long kb = atol(e);
+        if (kb >= 0 && kb <= 152)
+            c->lds_table_max = (size_t)kb * 1024;
+    }
+    *out = c;
+    return LUMAHIP_OK;
+}
+
+extern "C" void lumahip_destroy(lumahip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_frame);
+    (void)hipFree(c->d_planes);
+    (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_arr);
+    for (auto &sl : c->slot) {
+        (void)hipFree(sl.d_frame);
+        (void)hipFree(sl.d_planes);
+        (void)hipFree(sl.d_stats);
+        if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+        if (sl.kern) (void)hipEventDestroy(sl.kern);
+        if (sl.d2h) (void)hipEventDestroy(sl.d2h);
+    }
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    for (auto *st : {&c->stage_up[0], &c->stage_up[1], &c->stage_dn[0], &c->stage_dn[1]}) {
+        if (st->ev) (void)hipEventSynchronize(st->ev);
+        if (st->h) (void)hipHostFree(st->h);
+        if (st->ev) (void)hipEventDestroy(st->ev);
+    }
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_kern) (void)hipStreamDestroy(c->s_kern);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char *lumahip_last_error(const lumahip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int lumahip_set_stream(lumahip_ctx *c, void *s)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    c->stream = (hipStream_t)s;  // NULL is a valid handle: the device's default (null) stream
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_reset_stream(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    c->stream = c->own_stream;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_sync(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------- quantizer
+
+extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth, int cs, unsigned bitdepthC,
+                                     float maxLum, float minLum, const float *lut, size_t n)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (bitdepth < 1 || bitdepth > 16 || bitdepthC < 1 || bitdepthC > 16)
+        return fail(c, LUMAHIP_ERR_ARG, "bit depths must be 1..16 (got %u / %u)", bitdepth, bitdepthC);
+    if (!lut || n != ((size_t)1 << bitdepth))
+        return fail(c, LUMAHIP_ERR_ARG, "LUT must hold 2^bitdepth = %zu floats (got %zu)", (size_t)1 << bitdepth, n);
+    if (ptf < 0 || ptf > 4)
+        return fail(c, LUMAHIP_ERR_ARG, "unknown transfer function %d", ptf);
+    // an unknown colour space is accepted here, as in the reference (setQuantizer stores it blindly,
+    // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    // Search index.  Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit
+    // lds_table_max, else in global memory
+    // (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table)
+    // runs the reference's bisection literally.  LUMAHIP_FORCE_LITERAL is the tests' hook for that path.
+    c->tix = ThreshIndex();
+    // decode side: luminance table (+ Lu'v' chroma table, + the powf tables for YCbCr) staged in LDS
+    const size_t powf_b = (cs == CS_YCBCR) ? sizeof(PowfTablesWide) : 0;
+    c->lut_in_lds = bitdepthC <= 12 && (n + 4) * sizeof(float) <= std::max<size_t>(c->lds_table_max, 16 * 1024 + 16) &&
+                    (n + 4) * sizeof(float) + ((size_t)4 << bitdepthC) + 64 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP;
+    int mode = n <= 4096 ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
+    if (!getenv("LUMAHIP_FORCE_LITERAL")) {
+        c->tix = build_thresh_index(lut, (int)n, 1 << 19);
+        if (c->tix.ok)
+            mode = (c->tix.rec.size() * 4 <= c->lds_table_max && c->tix.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP)
+                       ? LUT_THRESH_LDS
+                       : LUT_THRESH_GLOBAL;
+    }
+    const size_t lut_floats = (n + 1 + 3) & ~(size_t)3;  // NaN padding up to a multiple of 16 bytes
+    std::vector<float> padded(lut_floats, __builtin_nanf(""));
+    memcpy(padded.data(), lut, n * sizeof(float));
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_rec);
+    c->d_lut = nullptr;
+    c->d_rec = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
+    if (c->tix.ok) {
+        std::vector<uint32_t> r((c->tix.rec.size() + 3) & ~(size_t)3, 0u);
+        memcpy(r.data(), c->tix.rec.data(), c->tix.rec.size() * sizeof(uint32_t));
+        HIPCHK(c, hipMalloc(&c->d_rec, r.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_rec, r.data(), r.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    QuantDev &q = c->q;
+    q.lut = c->d_lut;
+    q.rec = c->d_rec;
+    q.lut_len = (int)n;
+    q.pad = (int)(lut_floats - n);
+    q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
+    q.mode = mode;
+    q.shift = c->tix.ok ? c->tix.shift : 0;
+    q.kmin = c->tix.ok ? c->tix.kmin : 0;
+    q.nbuckets = c->tix.ok ? c->tix.nbuckets : 0;
+    q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);        // src/luma_quantizer.cpp:183
+    q.cs = cs;
+    q.Lmax = maxLum;
+    c->ptf = ptf;
+    c->bitdepth = bitdepth;
+    c->bitdepthC = bitdepthC;
+    c->minLum = minLum;
+    c->have_quant = true;
+    return LUMAHIP_OK;
+}
+
+// host-only view of the threshold records (no GPU, no context): info = {ok, mant_bits, shift, kmin, nbuckets}
+extern "C" int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap)
+{
+    if (!lut || !info || n < 2 || n > 65536)
+        return LUMAHIP_ERR_ARG;
+    const ThreshIndex ix = build_thresh_index(lut, (int)n, 1 << 19);
+    info[0] = ix.ok ? 1 : 0;
+    info[1] = ix.mant_bits;
+    info[2] = ix.shift;
+    info[3] = ix.kmin;
+    info[4] = ix.nbuckets;
+    if (rec_out && ix.ok) {
+        if (rec_cap < ix.rec.size())
+            return LUMAHIP_ERR_ARG;
+        memcpy(rec_out, ix.rec.data(), ix.rec.size() * sizeof(uint32_t));
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return LUMAHIP_ERR_STATE;
+    info[0] = c->q.mode;
+    info[1] = c->tix.ok ? c->tix.mant_bits : 0;
+    info[2] = c->q.nbuckets;
+    info[3] = c->tix.ok ? c->tix.shift : 0;
+    info[4] = (int)lds_bytes(c, true, c->q.cs);
+    return LUMAHIP_OK;
+}
+
+namespace lhost {
+
+// dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
+{
+    const QuantDev &q = c->q;
+    size_t b = 0;
+    const size_t lut_b = ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
+    if (encode_side) {
+        if (q.mode == LUT_LITERAL_LDS)
+            b += lut_b;
+        if (q.mode == LUT_THRESH_LDS)
+            b += ((size_t)q.nbuckets * 4 + 15) & ~(size_t)15;
+    } else if (c->lut_in_lds) {
+        b += lut_b;
+        if (cs_eff == CS_LUV)
+            b += (((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15;  // u'v' table of the Lu'v' decode kernels
+    }
+    if (cs_eff == CS_YCBCR)
+        b += sizeof(PowfTablesWide);
+    return b;
+}
+
+// Workgroup size of the fused kernels: 256 threads unless LUMAHIP_BLOCK says otherwise; search tables beyond
+// 32 KiB per workgroup would leave too few waves per CU at that size (160 KiB of LDS per CU), so the workgroup
+// grows with the table.
+//   - `few_waves` (the encode kernels of the HBM-bound colour spaces on long launches, see grid_for): three 256-thread
+//     workgroups per CU are the fastest configuration measured, so the workgroup stays at 256 threads as long as three
+//     copies of the table fit the CU's LDS (LOG-12's 42 KiB of records: 3.9 % faster than four 512-thread workgroups).
+int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves)
+{
+    if (c->block_forced)
+        return c->block_threads;
+    if (few_waves && c->block_threads == 256 && 3 * lds <= LUMAHIP_LDS_PER_WORKGROUP)
+        return 256;
+    if (lds > 53 * 1024)
+        return 1024;
+    if (lds > 32 * 1024)
+        return 512;
+    return c->block_threads;
+}
+
+int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff)
+{
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set (call lumahip_set_quantizer first)");
+    if (w == 0 || h == 0 || (w & 1) || (h & 1))
+        return fail(c, LUMAHIP_ERR_ARG, "Invalid frame size %ux%u (must be even, non-zero)", w, h);
+    if (profile < 0 || profile > 3)
+        return fail(c, LUMAHIP_ERR_ARG, "profile must be 0..3 (got %d)", profile);
+    if (cs_eff < 0 || cs_eff > CS_PACK)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", cs_eff);
+    return LUMAHIP_OK;
+}
+
+bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes)
+{
+    g.w = (int)w;
+    g.h = (int)h;
+    g.unitsX = (int)w / vw;
+    g.unitsY = (int)h / 2;
+    g.tilesX = (g.unitsX + 63) / 64;
+    g.tilesY = (g.unitsY + nw - 1) / nw;
+    g.tilesPerFrame = g.tilesX * g.tilesY;
+    const long long total = (long long)g.tilesPerFrame * nframes;
+    if (w > 0x7fffffffu / 4 || h > 0x7fffffffu / 4 || total > 0x7fffffffLL)
+        return false;  // tile indices are 32-bit
+    g.totalTiles = (int)total;
+    return true;
+}
+
+// Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  The default is 2048 threads' worth per CU (8
+// workgroups of 256), i.e. MORE than are resident at once for most kernels: the surplus is dispatched as resident ones
+// retire, which evens out the tail of short launches.  The rules below are for long (batched) launches, each one found by
+// running both settings in one process (tools/ab_inproc.py).  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute) and
+// LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers, bool ycbcr)
+{
+    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
+    // The 4:2:0 16-bit decode kernels write 12 of their 15 bytes per pixel, and fewer concurrent writers suit the memory
+    // system better: 5 workgroups of 256 threads per CU instead of 8 is 2.7-3.6 % faster on batched launches, both builds
+    // in one process (profiles/r02_grid_sweep.txt; the same change is 4 % SLOWER for 4:4:4 Lu'v' and 10 % slower for the
+    // 8-bit profiles, so it is theirs only).  Only where the launch is long enough for the coarser tail not to matter.
+    if (few_writers && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 12L * c->num_cu * 5)
+        per_cu = 5;
+    // The encode kernels with 256-thread workgroups (tables up to 32 KiB; not YCbCr, which is VALU-bound and wants the
+    // waves) run 3-6 % faster on long launches with 3 workgroups per CU than with 8 -- every colour space / profile
+    // variant, same build in one process (tools/ab_encode_grid.sh, profiles/r02_grid_sweep.txt); 6 per CU is 9 % SLOWER,
+    // 4 about as good as 3.  Fewer resident waves draw less power at the package limit and keep fewer streams open in the
+    // memory system.  Short launches keep 8 per CU for their tail.
+    if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 40L * c->num_cu * 3)
+        per_cu = 3;
+    // The YCbCr kernels are VALU-bound and only three of their 512-thread workgroups (49 KiB of LDS each) are resident
+    // per CU: many more, smaller static shares balance the CUs better than one share per resident workgroup -- 18 per CU
+    // is 4.9 % faster than 4 for encode, 12 per CU 4.3 % for decode (same build in one process, profiles/r02_grid_sweep.txt).
+    if (ycbcr && c->blocks_per_cu == 0 && threads == 512 && total_tiles >= 8L * c->num_cu * 18)
+        per_cu = dir == 0 ? 18 : 12;
+    long g = (long)c->num_cu * per_cu;
+    if (c->grid_override[dir] > 0)
+        g = c->grid_override[dir];
+    if (g > total_tiles)
+        g = total_tiles;
+    if (g < 1)
+        g = 1;
+    return (int)g;
+}
+
+// rows and bytes per row of plane p as vpx_img_alloc lays it out (src/luma_encoder.cpp:121-128)
+void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes)
+{
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    rows = (p && sub) ? (int)(h + 1) / 2 : (int)h;
+    row_bytes = ((p && sub) ? (int)(w + 1) / 2 : (int)w) * bps;
+}
+
+// the device entry points take caller-chosen strides: reject layouts in which rows or frames would overlap or the
+// kernels would write outside a plane (negative / too small strides, frame strides smaller than a frame)
+int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, size_t frame_stride,
+                        const int stride[3], const size_t pfs[3])
+{
+    for (int p = 0; p < 3; p++) {
+        int rows, row_bytes;
+        plane_dims(w, h, profile, p, rows, row_bytes);
+        if (stride[p] < row_bytes)
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: stride %d < row bytes %d", p, stride[p], row_bytes);
+        if (nframes > 1 && !c->allow_alias && pfs[p] < (size_t)rows * (size_t)stride[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: frame stride %zu < plane size %zu", p, pfs[p], (size_t)rows * stride[p]);
+    }
+    if (nframes > 1 && !c->allow_alias && frame_stride < (size_t)3 * w * h)
+        return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < 3*w*h = %zu floats", frame_stride, (size_t)3 * w * h);
+    return LUMAHIP_OK;
+}
+
+}  // namespace lhost
+
+// ---------------------------------------------------------------------------------------- memory helpers
+
+extern "C" int lumahip_host_register(lumahip_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_host_unregister(lumahip_ctx *c, void *p)
+{
+    if (!c || !p)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostUnregister(p));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_malloc(lumahip_ctx *c, void **p, size_t bytes)
+{
+    if (!c || !p)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(p, bytes));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_free(lumahip_ctx *c, void *p)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(p));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_memcpy_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = xfer_h2d(c, dst, src, bytes, c->stream);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_memcpy_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = xfer_d2h(c, dst, src, bytes, c->stream);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}

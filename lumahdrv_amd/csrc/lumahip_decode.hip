@@ -1,0 +1,238 @@
+// lumahip_decode.hip -- dispatch of the fused decode kernels (lh::k_decode, luma_kernels.hpp), with and without the display
+// epilogue, and the array forms of quantize / dequantize.
+#include "lumahip_internal.hpp"
+
+using namespace lh;
+using namespace lhost;
+
+namespace lh {
+// ---- array quantize / dequantize (LumaQuantizer::quantize / dequantize over arrays) ----------------
+struct QArrArgs {
+    QuantDev q;
+    const float *in;
+    float *out;
+    size_t n;
+    int lut_channel;  // 1: LUT path, 0: colour path
+};
+
+// MODE: the table's search mode (lut_index.hpp LutMode), a template parameter so that each instantiation stages
+// exactly what it probes
+template <int MODE>
+__global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    stage_tables<(MODE == 0 ? STAGE_LUT : 0) | (MODE == 3 ? STAGE_REC : 0)>(smem, a.q);
+    const float *s_lut = reinterpret_cast<const float *>(smem);
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v[1] = {a.in[i]};
+        int c[1];
+        if (!a.lut_channel)
+            c[0] = quantize_color(v[0], a.q.maxC);
+        else if constexpr (MODE == 3)
+            quantize_lut<3, 1>(v, c, s_lut, s_rec, a.q);     // any NaN sign
+        else if constexpr (MODE == 4)
+            quantize_lut<4, 1>(v, c, a.q.lut, a.q.rec, a.q);
+        else if constexpr (MODE == 0)
+            quantize_lut<0, 1>(v, c, s_lut, s_rec, a.q);
+        else
+            quantize_lut<2, 1>(v, c, a.q.lut, s_rec, a.q);
+        a.out[i] = (float)c[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
+{
+    // src/luma_quantizer.cpp:247-264 with a float argument (may be negative, fractional or NaN)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float val = a.in[i];
+        float res;
+        if (a.lut_channel) {
+            if (val < 0)
+                res = a.q.lut[0];
+            else if (val >= (float)a.q.maxVal)
+                res = a.q.lut[a.q.maxVal];
+            else
+                res = a.q.lut[(val != val) ? a.q.maxVal : (int)val];
+        } else {
+            res = std_max(div_ieee(val, a.q.maxC), 1e-10f);
+        }
+        a.out[i] = res;
+    }
+}
+
+}  // namespace lh
+
+typedef void (*dec_kernel_t)(const DecArgs);
+
+template <int CS, bool SUB>
+static dec_kernel_t pick_dec2(int vw, bool gl, bool disp)
+{
+    if (disp) {
+        if (gl)
+            return k_decode<CS, SUB, 2, true, true>;
+        return vw == 4 ? k_decode<CS, SUB, 4, false, true> : k_decode<CS, SUB, 2, false, true>;
+    }
+    if (gl)
+        return k_decode<CS, SUB, 2, true>;
+    return vw == 4 ? k_decode<CS, SUB, 4, false> : k_decode<CS, SUB, 2, false>;
+}
+
+static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp)
+{
+    switch (cs) {
+    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp) : pick_dec2<CS_LUV, false>(vw, gl, disp);
+    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp) : pick_dec2<CS_RGB, false>(vw, gl, disp);
+    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp) : pick_dec2<CS_YCBCR, false>(vw, gl, disp);
+    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp) : pick_dec2<CS_XYZ, false>(vw, gl, disp);
+    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp) : pick_dec2<CS_PACK, false>(vw, gl, disp);
+    }
+    return nullptr;
+}
+
+namespace lhost {
+
+int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                       unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
+                       const DisplayParams &dp, int cs_eff)
+{
+    if (!c || (!rgb && !dp.rgba) || !planes || !stride || !pfs || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, cs_eff);
+    if (rc)
+        return rc;
+    if ((rc = check_layout(c, w, h, profile, nframes, rgb ? frame_stride : (size_t)3 * w * h, stride, pfs)))
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    const bool gl = !c->lut_in_lds;
+    int vw = (!gl && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    if (dp.rgba && (!is_aligned(dp.rgba, 4) || (dp.stride % 4) != 0 || (dp.frame_stride % 4) != 0 || dp.stride < (int)(4 * w)))
+        return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
+    DecArgs a{};
+    a.q = c->q;
+    const size_t lds = lds_bytes(c, false, cs_eff);
+    const int threads = block_threads_for(c, lds);
+    if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
+    a.dst = rgb;
+    a.frame_stride = frame_stride;
+    a.sc = sc;
+    a.bps = bps;
+    a.aligned = 1;
+    a.disp = dp.rgba;
+    a.disp_stride = dp.stride;
+    a.disp_frame_stride = dp.frame_stride;
+    a.exposure = dp.exposure;
+    a.inv_gamma = 1.0f / dp.gamma;
+    a.do_tmo = dp.do_tmo;
+    a.ldr_sim = dp.ldr_sim;
+    for (int p = 0; p < 3; p++) {
+        if (!planes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "null plane %d", p);
+        a.src[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.src_frame_stride[p] = pfs[p];
+        const size_t ub = (size_t)((p && sub) ? vw / 2 : vw) * bps;
+        if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
+            a.aligned = 0;
+    }
+    a.q.cs = cs_eff;
+    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr, cs_eff == CS_YCBCR);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+
+int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    QArrArgs a{};
+    a.q = c->q;
+    a.in = d_in;
+    a.out = d_out;
+    a.n = n;
+    // src/luma_quantizer.cpp:219,251: LUT path for ch 0 and for every channel of RGB / XYZ
+    a.lut_channel = (ch == 0 || c->q.cs == CS_RGB || c->q.cs == CS_XYZ) ? 1 : 0;
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    if (quant) {
+        const size_t lds = lds_bytes(c, true, CS_PACK);  // no powf tables for the array kernels
+        void (*kern)(const QArrArgs) = k_quantize_array<2>;
+        switch (c->q.mode) {
+        case LUT_LITERAL_LDS: kern = k_quantize_array<0>; break;
+        case LUT_THRESH_LDS: kern = k_quantize_array<3>; break;
+        case LUT_THRESH_GLOBAL: kern = k_quantize_array<4>; break;
+        default: break;
+        }
+        if (lds > 64 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_dequantize_array, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+}  // namespace lhost
+
+extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                            float sc, float *rgb, size_t frame_stride)
+{
+    if (!rgb)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb, frame_stride, DisplayParams(), c->q.cs);
+}
+
+extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsigned char *const planes[3],
+                                                    const int stride[3], const size_t pfs[3], unsigned nframes, unsigned w,
+                                                    unsigned h, int profile, float sc, float *rgb_or_null,
+                                                    size_t frame_stride, unsigned char *rgba, int rgba_stride,
+                                                    size_t rgba_frame_stride, float exposure, float gamma, int do_tmo,
+                                                    int ldr_sim)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!rgba || !(gamma > 0.0f))
+        return fail(c, LUMAHIP_ERR_ARG, "display output needs a buffer and gamma > 0");
+    DisplayParams dp;
+    dp.rgba = rgba;
+    dp.stride = rgba_stride;
+    dp.frame_stride = rgba_frame_stride;
+    dp.exposure = exposure;
+    dp.gamma = gamma;
+    dp.do_tmo = do_tmo;
+    dp.ldr_sim = ldr_sim;
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_or_null, frame_stride, dp, c->q.cs);
+}
+
+extern "C" int lumahip_quantize_array_device(lumahip_ctx *c, const float *in_dev, float *out_dev, size_t n, unsigned ch)
+{
+    if (!c || !in_dev || !out_dev)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return n ? array_launch(c, in_dev, out_dev, n, ch, true) : LUMAHIP_OK;
+}
+
+extern "C" int lumahip_dequantize_array_device(lumahip_ctx *c, const float *in_dev, float *out_dev, size_t n, unsigned ch)
+{
+    if (!c || !in_dev || !out_dev)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return n ? array_launch(c, in_dev, out_dev, n, ch, false) : LUMAHIP_OK;
+}
+

@@ -1,0 +1,214 @@
+// lumahip_encode.hip -- dispatch of the fused encode kernels (lh::k_encode, luma_kernels.hpp) and of the other encode-side
+// instantiations: array quantize, the search probe, the traffic-only probe.
+#include "lumahip_internal.hpp"
+
+using namespace lh;
+using namespace lhost;
+
+namespace lh {
+// Traffic probe: the loads and stores of k_encode<.,4:2:0,VW=4> for 16-bit planes with NO arithmetic (an xor
+// keeps every loaded word live).  Its run time is what the memory system alone needs for the encode traffic mix
+// (12 B read + 3 B written per pixel, same tile order, same non-temporal accesses); bench.py reports the encode
+// kernel's time as a fraction of it next to the fraction of the 8 TB/s peak.
+__global__ __launch_bounds__(256) void k_encode_traffic_probe(const EncArgs a)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const size_t cs = (size_t)a.g.w * a.g.h;
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
+        int f, bx, by;
+        tile_coords(t, a.g, f, bx, by);
+        const int ux = bx * 64 + tx, uy = by * NW + ty;
+        if (ux >= a.g.unitsX || uy >= a.g.unitsY)
+            continue;
+        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * 4;
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                float v[4];
+                load_px<4>(p + c * cs + (size_t)r * a.g.w, v);
+                q0 ^= __float_as_uint(v[0]); q1 ^= __float_as_uint(v[1]); q2 ^= __float_as_uint(v[2]); q3 ^= __float_as_uint(v[3]);
+            }
+        unsigned char *d0 = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * 8;
+        nt_store_u32x2(d0, q0, q1);
+        nt_store_u32x2(d0 + a.stride[0], q2, q3);
+        nt_store_u32(a.dst[1] + (size_t)f * a.dst_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * 4, q0 ^ q2);
+        nt_store_u32(a.dst[2] + (size_t)f * a.dst_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * 4, q1 ^ q3);
+    }
+}
+
+}  // namespace lh
+
+typedef void (*enc_kernel_t)(const EncArgs);
+
+template <int CS, bool SUB>
+static enc_kernel_t pick_enc2(int vw, int mode)
+{
+    if (mode == LUT_THRESH_LDS)
+        return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
+    if (mode == LUT_THRESH_GLOBAL)
+        return vw == 4 ? k_encode<CS, SUB, 4, 4> : k_encode<CS, SUB, 2, 4>;
+    if (mode == LUT_LITERAL_LDS)
+        return k_encode<CS, SUB, 2, 0>;
+    return k_encode<CS, SUB, 2, 2>;
+}
+
+static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
+{
+    switch (cs) {
+    case CS_LUV: return sub ? pick_enc2<CS_LUV, true>(vw, mode) : pick_enc2<CS_LUV, false>(vw, mode);
+    case CS_RGB: return sub ? pick_enc2<CS_RGB, true>(vw, mode) : pick_enc2<CS_RGB, false>(vw, mode);
+    case CS_YCBCR: return sub ? pick_enc2<CS_YCBCR, true>(vw, mode) : pick_enc2<CS_YCBCR, false>(vw, mode);
+    case CS_XYZ: return sub ? pick_enc2<CS_XYZ, true>(vw, mode) : pick_enc2<CS_XYZ, false>(vw, mode);
+    case CS_PACK: return sub ? pick_enc2<CS_PACK, true>(vw, mode) : pick_enc2<CS_PACK, false>(vw, mode);
+    }
+    return nullptr;
+}
+
+__global__ void k_init_stats(float *s, int nframes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nframes) {
+        s[3 * i + 0] = 0.0f;
+        s[3 * i + 1] = __builtin_inff();
+        s[3 * i + 2] = -__builtin_inff();
+    }
+}
+
+namespace lhost {
+
+int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w,
+                                     unsigned h, float sc, int profile, unsigned char *const planes[3], const int stride[3],
+                                     const size_t pfs[3], float *stats, int cs_eff)
+{
+    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, cs_eff);
+    if (rc)
+        return rc;
+    if ((rc = check_layout(c, w, h, profile, nframes, frame_stride, stride, pfs)))
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    const int mode = c->q.mode;
+    const bool fast_search = (mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
+    int vw = (fast_search && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    EncArgs a{};
+    a.q = c->q;
+    const size_t lds = lds_bytes(c, true, cs_eff);
+    const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
+    const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
+    if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
+    a.src = rgb;
+    a.frame_stride = frame_stride;
+    a.sc = sc;
+    a.bps = bps;
+    a.stats = stats;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        if (!planes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "null plane %d", p);
+        a.dst[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.dst_frame_stride[p] = pfs[p];
+        const size_t ub = (size_t)((p && sub) ? vw / 2 : vw) * bps;
+        if (!is_aligned(planes[p], ub) || (stride[p] % (int)ub) != 0 || (pfs[p] % ub) != 0)
+            a.aligned = 0;
+    }
+    a.q.cs = cs_eff;
+    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
+    if (stats)
+        hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+}  // namespace lhost
+
+extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
+                                            unsigned w, unsigned h, float sc, int profile,
+                                            unsigned char *const planes[3], const int stride[3],
+                                            const size_t pfs[3], float *stats)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return encode_frames_device_impl(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+}
+
+extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
+                                                   unsigned w, unsigned h, unsigned char *const planes[3],
+                                                   const int stride[3], const size_t pfs[3], int iters, float *avg_ms)
+{
+    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0 || iters <= 0 || !avg_ms)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (w == 0 || h == 0 || (w % 4) || (h & 1) || !is_aligned(rgb, 16) || (frame_stride % 4))
+        return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs w %% 4 == 0, even h and 16-byte aligned frames");
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || !is_aligned(planes[p], 8) || (stride[p] % (p ? 4 : 8)) || (pfs[p] % 8))
+            return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs 8-byte aligned 16-bit 4:2:0 planes");
+    HIPCHK(c, hipSetDevice(c->device));
+    EncArgs a{};
+    const int threads = 256;
+    if (!make_geom(a.g, w, h, 4, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large");
+    a.src = rgb;
+    a.frame_stride = frame_stride;
+    a.bps = 2;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        a.dst[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.dst_frame_stride[p] = pfs[p];
+    }
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0);
+    EventPair ev;
+    HIPCHK(c, ev.create());
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_encode_traffic_probe, dim3(grid), dim3(threads), 0, c->stream, a);
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    HIPCHK(c, hipGetLastError());
+    *avg_ms = ms / iters;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg)
+{
+    if (!c || !out_dev || n == 0 || (n % 4) != 0 || !is_aligned(out_dev, 8))
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument (n must be a multiple of 4, out 8-byte aligned)");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t lds = lds_bytes(c, true, CS_PACK);
+    void (*kern)(const QuantDev, uint16_t *, uint32_t, size_t) = nullptr;
+    switch (c->q.mode) {
+    case LUT_LITERAL_LDS: kern = nonneg ? k_quantize_probe<0, true> : k_quantize_probe<0, false>; break;
+    case LUT_LITERAL_GLOBAL: kern = nonneg ? k_quantize_probe<2, true> : k_quantize_probe<2, false>; break;
+    case LUT_THRESH_LDS: kern = nonneg ? k_quantize_probe<3, true> : k_quantize_probe<3, false>; break;
+    case LUT_THRESH_GLOBAL: kern = nonneg ? k_quantize_probe<4, true> : k_quantize_probe<4, false>; break;
+    }
+    if (!kern)
+        return fail(c, LUMAHIP_ERR_STATE, "unknown search mode %d", c->q.mode);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long grid = (long)((n / 4 + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, c->stream, c->q, out_dev, first_bits, n / 4);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+

@@ -1,0 +1,599 @@
+// lumahip_host.hip -- the _host entry points of include/lumahip.h: staging buffers, host <-> device transfers, the 3-slot
+// pipeline of the batched forms.  No kernels here.
+#include "lumahip_internal.hpp"
+
+using namespace lh;
+using namespace lhost;
+
+// ---- host <-> device transfers of the _host entry points --------------------------------------------------------
+// Caller memory is pageable unless the caller pinned it (hipHostMalloc, hipHostRegister / lumahip_host_register).
+// Pinned memory is handed to the copy engine directly (asynchronous, the fast path of the batched entry points).
+// Pageable memory is NOT handed to hipMemcpy*Async: the runtime then pins the caller's pages on the fly and caches
+// that pinning, and on this stack (ROCm 7.2, MI355X) the GPU occasionally faulted on such a range when host buffers are
+// allocated and freed at a high rate ("Memory access fault by GPU ... on address <host heap page>", about one run of
+// the GPU test suite in twenty).  Pageable data therefore moves through two context-owned pinned chunks per direction:
+// the CPU copy of chunk k+1 overlaps the DMA of chunk k.
+static constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+
+static bool host_range_is_pinned(const void *p, size_t bytes)
+{
+    if (!p || !bytes)
+        return false;
+    const unsigned char *ends[2] = {(const unsigned char *)p, (const unsigned char *)p + bytes - 1};
+    for (const unsigned char *q : ends) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();  // plain malloc memory: not an error of ours
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost)
+            return false;
+    }
+    return true;
+}
+
+static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
+{
+    if (!st.h) {
+        HIPCHK(c, hipHostMalloc((void **)&st.h, XFER_CHUNK, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    }
+    if (st.pending) {
+        HIPCHK(c, hipEventSynchronize(st.ev));
+        st.pending = false;
+    }
+    return LUMAHIP_OK;
+}
+
+// rows x width bytes, host pitch hp, device pitch dp.  Returns once the copies are queued on `s` (the caller's buffer
+// is no longer needed if it was pageable: it has been copied into the staging chunks).
+static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, size_t hp, size_t width, size_t rows, hipStream_t s)
+{
+    if (!width || !rows)
+        return LUMAHIP_OK;
+    if (host_range_is_pinned(src, (rows - 1) * hp + width)) {
+        if (dp == width && hp == width)
+            HIPCHK(c, hipMemcpyAsync(dst, src, width * rows, hipMemcpyHostToDevice, s));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dst, dp, src, hp, width, rows, hipMemcpyHostToDevice, s));
+        return LUMAHIP_OK;
+    }
+    // staged: the device side is written as whole rows of dp bytes (the padding between rows belongs to the context's
+    // own buffers), so that one chunk is one contiguous DMA
+    const bool flat = (dp == width && hp == width);
+    if (!flat && dp > XFER_CHUNK)
+        return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
+    const size_t total = flat ? width * rows : rows;                 // bytes or rows
+    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;          // per chunk
+    int k = 0;
+    for (size_t done = 0; done < total; k++) {
+        lumahip_ctx::Stage &st = c->stage_up[k & 1];
+        int rc = stage_ready(c, st);
+        if (rc)
+            return rc;
+        const size_t n = total - done < per ? total - done : per;
+        size_t bytes;
+        if (flat) {
+            memcpy(st.h, (const unsigned char *)src + done, n);
+            bytes = n;
+        } else {
+            for (size_t r = 0; r < n; r++)
+                memcpy(st.h + r * dp, (const unsigned char *)src + (done + r) * hp, width);
+            bytes = (n - 1) * dp + width;
+        }
+        HIPCHK(c, hipMemcpyAsync((unsigned char *)dst + done * (flat ? 1 : dp), st.h, bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(st.ev, s));
+        st.pending = true;
+        done += n;
+    }
+    return LUMAHIP_OK;
+}
+
+namespace lhost {
+
+int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    return xfer_h2d_2d(c, dst, bytes, src, bytes, bytes, 1, s);
+}
+
+}
+
+// Device -> host.  Pinned destination: queued on `s`, the caller synchronises.  Pageable destination: the data is in
+// `dst` when the call returns (everything queued on `s` before it has completed by then).
+static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, size_t dp, size_t width, size_t rows, hipStream_t s)
+{
+    if (!width || !rows)
+        return LUMAHIP_OK;
+    if (host_range_is_pinned(dst, (rows - 1) * hp + width)) {
+        if (dp == width && hp == width)
+            HIPCHK(c, hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToHost, s));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dst, hp, src, dp, width, rows, hipMemcpyDeviceToHost, s));
+        return LUMAHIP_OK;
+    }
+    const bool flat = (dp == width && hp == width);
+    if (!flat && dp > XFER_CHUNK)
+        return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
+    const size_t total = flat ? width * rows : rows;
+    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;
+    size_t prev_done = 0, prev_n = 0;
+    int k = 0;
+    auto drain = [&](lumahip_ctx::Stage &st, size_t at, size_t n) -> int {
+        HIPCHK(c, hipEventSynchronize(st.ev));
+        st.pending = false;
+        if (flat) {
+            memcpy((unsigned char *)dst + at, st.h, n);
+        } else {
+            for (size_t r = 0; r < n; r++)
+                memcpy((unsigned char *)dst + (at + r) * hp, st.h + r * dp, width);
+        }
+        return LUMAHIP_OK;
+    };
+    for (size_t done = 0; done < total; k++) {
+        lumahip_ctx::Stage &st = c->stage_dn[k & 1];
+        int rc = stage_ready(c, st);
+        if (rc)
+            return rc;
+        const size_t n = total - done < per ? total - done : per;
+        const size_t bytes = flat ? n : (n - 1) * dp + width;
+        HIPCHK(c, hipMemcpyAsync(st.h, (const unsigned char *)src + done * (flat ? 1 : dp), bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(st.ev, s));
+        st.pending = true;
+        if (k > 0 && (rc = drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n)))
+            return rc;
+        prev_done = done;
+        prev_n = n;
+        done += n;
+    }
+    return drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n);
+}
+
+namespace lhost {
+
+int xfer_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    return xfer_d2h_2d(c, dst, bytes, src, bytes, bytes, 1, s);
+}
+
+// a few floats from the device: through the pinned scratch, synchronous
+int read_small(lumahip_ctx *c, float *dst, const float *src_dev, int n, hipStream_t s)
+{
+    if (!c->h_small)
+        HIPCHK(c, hipHostMalloc((void **)&c->h_small, 64 * sizeof(float), hipHostMallocDefault));
+    HIPCHK(c, hipMemcpyAsync(c->h_small, src_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(dst, c->h_small, (size_t)n * sizeof(float));
+    return LUMAHIP_OK;
+}
+
+int ensure(lumahip_ctx *c, void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need)
+        return LUMAHIP_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc(p, need));
+    *cap = need;
+    return LUMAHIP_OK;
+}
+
+}  // namespace lhost
+
+struct PlaneLayout {
+    int rows[3];
+    int row_bytes[3];
+    size_t off[3];
+    size_t total;
+};
+
+static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, const int stride[3])
+{
+    const bool sub = (profile == 0 || profile == 2);
+    const int bps = profile > 1 ? 2 : 1;
+    size_t off = 0;
+    for (int p = 0; p < 3; p++) {
+        const int pw = (p && sub) ? (int)(w + 1) / 2 : (int)w;
+        const int ph = (p && sub) ? (int)(h + 1) / 2 : (int)h;
+        L.rows[p] = ph;
+        L.row_bytes[p] = pw * bps;
+        L.off[p] = off;
+        off += ((size_t)ph * stride[p] + 255) & ~(size_t)255;
+    }
+    L.total = off;
+}
+
+// The reference warns when its (sequentially summed) mean luminance is <= 1.  That fp32 sum is far from the true sum on
+// large frames: once the running sum S is large, addends below ulp(S)/2 vanish and the rest are rounded to multiples of
+// ulp(S) (measured: -0.2 % at 1080p, several % at 4K on wide-range content), whereas the kernels' statistic (per-wave
+// partial sums) is accurate to ~1e-6.  Around the threshold S stays below N * 4, i.e. ulp(S)/2 <= 2 up to 8K frames, so
+// the two can only disagree about `<= 1` when the accurate mean lies in [0.25, 4]: inside that band the host entry points
+// replace the statistic by the reference's exact value (k_seq_sum), outside it the decision is the same either way.
+static bool mean_near_threshold(float m) { return m >= 0.25f && m <= 4.0f; }
+
+static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                  unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                                  float *transformed_out, int cs_eff)
+{
+    if (!c || !rgb || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, cs_eff);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int bps = profile > 1 ? 2 : 1;
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride %d < row bytes %d", p, stride[p], L.row_bytes[p]);
+    (void)bps;
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, nfl * sizeof(float))))
+        return rc;
+    if ((rc = ensure(c, (void **)&c->d_planes, &c->d_planes_cap, L.total)))
+        return rc;
+    if (!c->d_stats)
+        HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
+    if ((rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
+        return rc;
+    unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
+    const size_t pfs[3] = {0, 0, 0};
+    rc = encode_frames_device_impl(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
+    if (rc)
+        return rc;
+    for (int p = 0; p < 3; p++)
+        if ((rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+            return rc;
+    if (transformed_out) {
+        rc = lumahip_transform_color_space_device(c, c->d_frame, nfl, 1, w, h, 1, sc);
+        if (rc)
+            return rc;
+        if ((rc = xfer_d2h(c, transformed_out, c->d_frame, nfl * sizeof(float), c->stream)))
+            return rc;
+    }
+    float st[3] = {0, 0, 0};
+    if ((rc = read_small(c, st, c->d_stats, 3, c->stream)))  // synchronises the stream
+        return rc;
+    if (mean_lum) {
+        *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
+        if (mean_near_threshold(*mean_lum))  // d_frame holds the caller's frame, or already its transformed version
+            return transformed_out ? seq_mean(c, c->d_frame, w, h, mean_lum)
+                                   : mean_luminance_reference_impl(c, c->d_frame, w, h, sc, cs_eff, mean_lum);
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_encode_frame_host(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                         unsigned char *const planes[3], const int stride[3], float *mean_lum,
+                                         float *transformed_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return encode_frame_host_impl(c, rgb, w, h, sc, profile, planes, stride, mean_lum, transformed_out, c->q.cs);
+}
+
+static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], unsigned w,
+                                  unsigned h, int profile, float sc, float *rgb_out, int cs_eff)
+{
+    if (!c || !rgb_out || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, cs_eff);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride %d < row bytes %d", p, stride[p], L.row_bytes[p]);
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, nfl * sizeof(float))))
+        return rc;
+    if ((rc = ensure(c, (void **)&c->d_planes, &c->d_planes_cap, L.total)))
+        return rc;
+    unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
+    for (int p = 0; p < 3; p++)
+        if ((rc = xfer_h2d_2d(c, dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+            return rc;
+    const size_t pfs[3] = {0, 0, 0};
+    rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl, DisplayParams(), cs_eff);
+    if (rc)
+        return rc;
+    if ((rc = xfer_d2h(c, rgb_out, c->d_frame, nfl * sizeof(float), c->stream)))
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                         unsigned w, unsigned h, int profile, float sc, float *rgb_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return decode_frame_host_impl(c, planes, stride, w, h, profile, sc, rgb_out, c->q.cs);
+}
+
+// ---- batched host entry points: a 3-slot software pipeline over three streams.  Frame i's H2D copy runs while
+// frame i-1's kernel and frame i-2's D2H copies are in flight; with pinned caller memory (lumahip_host_register) the
+// two copy directions overlap as well and the rate approaches the PCIe H2D rate.
+static int pipe_prepare(lumahip_ctx *c, size_t frame_bytes, size_t planes_bytes, unsigned nframes)
+{
+    if (!c->s_h2d) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_kern, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+        for (auto &sl : c->slot) {
+            HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.kern, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.d2h, hipEventDisableTiming));
+            HIPCHK(c, hipMalloc(&sl.d_stats, 3 * sizeof(float)));
+        }
+    }
+    if (c->slot_frame_cap < frame_bytes || c->slot_planes_cap < planes_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &sl : c->slot) {
+            (void)hipFree(sl.d_frame);
+            (void)hipFree(sl.d_planes);
+            sl.d_frame = nullptr;
+            sl.d_planes = nullptr;
+            HIPCHK(c, hipMalloc(&sl.d_frame, frame_bytes));
+            HIPCHK(c, hipMalloc(&sl.d_planes, planes_bytes));
+        }
+        c->slot_frame_cap = frame_bytes;
+        c->slot_planes_cap = planes_bytes;
+    }
+    if (c->h_stats_cap < nframes) {
+        if (c->h_stats)
+            (void)hipHostFree(c->h_stats);
+        c->h_stats = nullptr;
+        HIPCHK(c, hipHostMalloc(&c->h_stats, (size_t)nframes * 3 * sizeof(float), hipHostMallocDefault));
+        c->h_stats_cap = nframes;
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rgb, unsigned nframes, unsigned w, unsigned h,
+                                          float sc, int profile, unsigned char *const *planes, const int stride[3],
+                                          float *mean_lum)
+{
+    if (!c || !rgb || !planes || !stride || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, c->q.cs);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (unsigned i = 0; i < nframes; i++) {
+        if (!rgb[i])
+            return fail(c, LUMAHIP_ERR_ARG, "null frame %u", i);
+        for (int p = 0; p < 3; p++)
+            if (!planes[3 * i + p] || stride[p] < L.row_bytes[p])
+                return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
+    }
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
+        return rc;
+    hipStream_t saved = c->stream;
+    const size_t pfs[3] = {0, 0, 0};
+    // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched: with pageable planes the fetch
+    // blocks the host (xfer_d2h_2d), and this order keeps the GPU busy with frame i meanwhile.
+    auto fetch = [&](unsigned i) -> int {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        int r = LUMAHIP_OK;
+        for (int p = 0; p < 3 && r == LUMAHIP_OK; p++)
+            r = xfer_d2h_2d(c, planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h);
+        if (r)
+            return r;
+        (void)hipMemcpyAsync(c->h_stats + 3 * (size_t)i, sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        return LUMAHIP_OK;
+    };
+    for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        if (i >= 3) {
+            // slot reuse: the kernel of frame i-3 must have consumed d_frame, its D2H must have drained d_planes
+            (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);
+            (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
+        }
+        if ((rc = xfer_h2d(c, sl.d_frame, rgb[i], nfl * sizeof(float), c->s_h2d)))
+            break;
+        (void)hipEventRecord(sl.h2d, c->s_h2d);
+        (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+        c->stream = c->s_kern;
+        rc = lumahip_encode_frames_device(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+        c->stream = saved;
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.kern, c->s_kern);
+        if (i >= 1)
+            rc = fetch(i - 1);
+    }
+    if (rc == LUMAHIP_OK)
+        rc = fetch(nframes - 1);
+    c->stream = saved;
+    HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+    HIPCHK(c, hipStreamSynchronize(c->s_kern));
+    HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+    if (rc == LUMAHIP_OK && mean_lum)
+        for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
+            mean_lum[i] = c->h_stats[3 * (size_t)i] / (float)((int)w * (int)h);
+            if (mean_near_threshold(mean_lum[i])) {  // rare: redo this frame's sum in the reference's order
+                if ((rc = xfer_h2d(c, c->slot[0].d_frame, rgb[i], nfl * sizeof(float), c->stream)))
+                    return rc;
+                rc = mean_luminance_reference_impl(c, c->slot[0].d_frame, w, h, sc, c->q.cs, &mean_lum[i]);
+            }
+        }
+    return rc;
+}
+
+extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *const *planes, const int stride[3],
+                                          unsigned nframes, unsigned w, unsigned h, int profile, float sc,
+                                          float *const *rgb_out)
+{
+    if (!c || !rgb_out || !planes || !stride || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, c->q.cs);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (unsigned i = 0; i < nframes; i++) {
+        if (!rgb_out[i])
+            return fail(c, LUMAHIP_ERR_ARG, "null output frame %u", i);
+        for (int p = 0; p < 3; p++)
+            if (!planes[3 * i + p] || stride[p] < L.row_bytes[p])
+                return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
+    }
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
+        return rc;
+    hipStream_t saved = c->stream;
+    const size_t pfs[3] = {0, 0, 0};
+    auto fetch = [&](unsigned i) -> int {  // as in lumahip_encode_frames_host: frame i-1 is fetched after frame i is queued
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+        int r = xfer_d2h(c, rgb_out[i], sl.d_frame, nfl * sizeof(float), c->s_d2h);
+        if (r)
+            return r;
+        (void)hipEventRecord(sl.d2h, c->s_d2h);
+        return LUMAHIP_OK;
+    };
+    for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
+        lumahip_ctx::Slot &sl = c->slot[i % 3];
+        unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+        if (i >= 3) {
+            (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);   // planes of frame i-3 consumed
+            (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);   // floats of frame i-3 copied out
+        }
+        for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++)
+            rc = xfer_h2d_2d(c, dp[p], stride[p], planes[3 * i + p], stride[p], L.row_bytes[p], L.rows[p], c->s_h2d);
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.h2d, c->s_h2d);
+        (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+        c->stream = c->s_kern;
+        rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
+        c->stream = saved;
+        if (rc)
+            break;
+        (void)hipEventRecord(sl.kern, c->s_kern);
+        if (i >= 1)
+            rc = fetch(i - 1);
+    }
+    if (rc == LUMAHIP_OK)
+        rc = fetch(nframes - 1);
+    c->stream = saved;
+    HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+    HIPCHK(c, hipStreamSynchronize(c->s_kern));
+    HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+    return rc;
+}
+
+extern "C" int lumahip_transform_color_space_host(lumahip_ctx *c, float *frame, unsigned w, unsigned h, int toCs, float sc)
+{
+    if (!c || !frame)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (c->q.cs < 0 || c->q.cs > 3)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Error! Unrecognized color transformation");
+    if (w == 0 || h == 0)
+        return LUMAHIP_OK;  // the reference loops zero times and returns true
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h, nfl = 3 * n;
+    // device copy padded to an even pixel count per channel so the pair kernel applies to odd sizes too
+    const size_t npad = (n + 1) & ~(size_t)1;
+    int rc = ensure(c, (void **)&c->d_frame, &c->d_frame_cap, 3 * npad * sizeof(float));
+    if (rc)
+        return rc;
+    if (npad == n) {
+        if ((rc = xfer_h2d(c, c->d_frame, frame, nfl * sizeof(float), c->stream)))
+            return rc;
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_frame, 0, 3 * npad * sizeof(float), c->stream));
+        for (int ch = 0; ch < 3; ch++)
+            if ((rc = xfer_h2d(c, c->d_frame + ch * npad, frame + ch * n, n * sizeof(float), c->stream)))
+                return rc;
+    }
+    // the kernel addresses channels at chan_stride = (w*h); present the padded buffer as a (npad x 1) frame
+    rc = lumahip_transform_color_space_device(c, c->d_frame, 3 * npad, 1, (unsigned)npad, 1, toCs, sc);
+    if (rc)
+        return rc;
+    if (npad == n) {
+        if ((rc = xfer_d2h(c, frame, c->d_frame, nfl * sizeof(float), c->stream)))
+            return rc;
+    } else {
+        for (int ch = 0; ch < 3; ch++)
+            if ((rc = xfer_d2h(c, frame + ch * n, c->d_frame + ch * npad, n * sizeof(float), c->stream)))
+                return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+static int array_op(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch, bool quant)
+{
+    if (!c || !in || !out)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (n == 0)
+        return LUMAHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, 2 * n * sizeof(float));
+    if (rc)
+        return rc;
+    if ((rc = xfer_h2d(c, c->d_arr, in, n * sizeof(float), c->stream)))
+        return rc;
+    if ((rc = array_launch(c, c->d_arr, c->d_arr + n, n, ch, quant)))
+        return rc;
+    if ((rc = xfer_d2h(c, out, c->d_arr + n, n * sizeof(float), c->stream)))
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_quantize_array_host(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch)
+{
+    return array_op(c, in, out, n, ch, true);
+}
+
+extern "C" int lumahip_dequantize_array_host(lumahip_ctx *c, const float *in, float *out, size_t n, unsigned ch)
+{
+    return array_op(c, in, out, n, ch, false);
+}
+
+// LumaEncoder::setChannels / LumaDecoder::getVpxChannels on their own: no colour transform.  Channel 0
+// goes through the LUT; channels 1,2 through the LUT for RGB / XYZ (src/luma_quantizer.cpp:219,251) --
+// which is the CS_RGB kernel with sc = 1 (x*1.0f and x/1.0f are exact) -- and through the colour quantizer
+// otherwise (CS_PACK).
+static int pack_cs(const lumahip_ctx *c) { return (c->q.cs == CS_RGB || c->q.cs == CS_XYZ) ? CS_RGB : CS_PACK; }
+
+extern "C" int lumahip_pack_frame_host(lumahip_ctx *c, const float *transformed, unsigned w, unsigned h, int profile,
+                                       unsigned char *const planes[3], const int stride[3], float *mean_lum)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return encode_frame_host_impl(c, transformed, w, h, 1.0f, profile, planes, stride, mean_lum, nullptr, pack_cs(c));
+}
+
+extern "C" int lumahip_unpack_frame_host(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                         unsigned w, unsigned h, int profile, float *dequantized_out)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    return decode_frame_host_impl(c, planes, stride, w, h, profile, 1.0f, dequantized_out, pack_cs(c));
+}
+

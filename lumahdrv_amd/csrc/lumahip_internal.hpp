@@ -1,0 +1,158 @@
+// lumahip_internal.hpp -- what the translation units behind include/lumahip.h share: the context, error helpers,
+// launch-geometry rules and the device-side implementations the host entry points call.  Not installed, not part of the ABI.
+//
+//   lumahip_core.hip    context life cycle, quantizer upload, launch-geometry rules, memory helpers       (no kernels)
+//   lumahip_encode.hip  every k_encode / encode-side instantiation and its dispatch
+//   lumahip_decode.hip  every k_decode instantiation and its dispatch
+//   lumahip_misc.hip    stand-alone transform, synthetic frames, the reference's mean luminance, probes, timing helper
+//   lumahip_host.hip    the _host entry points: staging, host <-> device transfers, the 3-slot pipeline   (no kernels)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lumahip.h"
+#include "luma_kernels.hpp"
+#include "lut_index.hpp"
+
+// Largest search table (encode: threshold records, decode: the luminance table) a workgroup stages in LDS; beyond it
+// the table is read from global memory (L2-resident).  gfx950 has 160 KiB of LDS per CU; tables beyond 53 KiB run as one
+// or two 1024-thread workgroups per CU -- for the 136 KiB of PQ 13-bit records that is still twice as fast as gathering
+// them from L2 (346 against 182 Gpixel/s, profiles/r02_perf_matrix.txt).  LUMAHIP_LDS_TABLE_MAX_KB overrides it.
+static constexpr size_t LUMAHIP_LDS_TABLE_MAX_DEFAULT = 144 * 1024;
+static constexpr size_t LUMAHIP_LDS_PER_WORKGROUP = 160 * 1024;
+
+struct lumahip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cu = 256;
+
+    bool have_quant = false;
+    int ptf = 0;
+    unsigned bitdepth = 0, bitdepthC = 0;
+    lh::QuantDev q{};
+    lh::ThreshIndex tix;
+    float *d_lut = nullptr;
+    uint32_t *d_rec = nullptr;
+    bool lut_in_lds = true;  // decode side: tables up to 12 bits are staged in LDS
+    float minLum = 0.0f;
+
+    // staging for the _host entry points
+    float *d_frame = nullptr;
+    size_t d_frame_cap = 0;
+    unsigned char *d_planes = nullptr;
+    size_t d_planes_cap = 0;
+    float *d_stats = nullptr;
+    float *d_arr = nullptr;
+    size_t d_arr_cap = 0;
+
+    // 3-slot pipeline of the batched host entry points (H2D / kernel / D2H on three streams)
+    struct Slot {
+        float *d_frame = nullptr;
+        unsigned char *d_planes = nullptr;
+        float *d_stats = nullptr;
+        hipEvent_t h2d = nullptr, kern = nullptr, d2h = nullptr;
+    } slot[3];
+    size_t slot_frame_cap = 0, slot_planes_cap = 0;
+    hipStream_t s_h2d = nullptr, s_kern = nullptr, s_d2h = nullptr;
+    float *h_stats = nullptr;  // pinned, 3 floats per frame
+    size_t h_stats_cap = 0;
+
+    // Pinned staging for pageable caller memory (see xfer_h2d): two chunks per direction, ping-pong
+    struct Stage {
+        unsigned char *h = nullptr;
+        hipEvent_t ev = nullptr;
+        bool pending = false;  // a DMA that reads / writes this chunk may still be in flight
+    } stage_up[2], stage_dn[2];
+    float *h_small = nullptr;  // pinned scratch for the few-float readbacks
+
+    int block_threads = 256;
+    bool block_forced = false;
+    bool allow_alias = false;  // LUMAHIP_ALLOW_ALIASED_FRAMES=1: measurement tools alias all frames of a batch onto one
+    int blocks_per_cu = 0;  // 0 = occupancy query
+    long grid_override[2] = {0, 0};
+    size_t lds_table_max = LUMAHIP_LDS_TABLE_MAX_DEFAULT;
+};
+
+int lumahip_fail(lumahip_ctx *c, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+#define fail lumahip_fail
+
+#define HIPCHK(c, expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail((c), LUMAHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                             \
+    } while (0)
+
+
+namespace lhost {
+using namespace lh;
+
+static inline bool is_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+// a pair of timing events that cannot leak on an early return
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create()
+    {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+
+struct DisplayParams {
+    unsigned char *rgba = nullptr;
+    int stride = 0;
+    size_t frame_stride = 0;
+    float exposure = 1.0f, gamma = 2.2f;
+    int do_tmo = 0, ldr_sim = 0;
+};
+
+// ---- lumahip_core.hip
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff);
+int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
+int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
+bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false);
+void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes);
+int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, size_t frame_stride,
+                 const int stride[3], const size_t pfs[3]);
+
+// ---- lumahip_encode.hip / lumahip_decode.hip: cs_eff = the colour space the kernels run (the context's, or CS_PACK /
+// CS_RGB for the pack-only entry points)
+int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w,
+                              unsigned h, float sc, int profile, unsigned char *const planes[3], const int stride[3],
+                              const size_t pfs[3], float *stats, int cs_eff);
+int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
+                const DisplayParams &dp, int cs_eff);
+int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant);
+
+// ---- lumahip_misc.hip
+int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned h, float *mean_host);
+int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc, int cs_eff,
+                                  float *mean_host);
+
+// ---- lumahip_host.hip
+int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s);
+int xfer_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s);
+int read_small(lumahip_ctx *c, float *dst, const float *src_dev, int n, hipStream_t s);
+int ensure(lumahip_ctx *c, void **p, size_t *cap, size_t need);
+
+}  // namespace lhost

@@ -1,0 +1,234 @@
+// lumahip_misc.hip -- the kernels around the two fused ones: stand-alone colour transform, synthetic frames, the reference's
+// sequential mean luminance, the powf probe, the launch-timing helper.
+#include "lumahip_internal.hpp"
+
+using namespace lh;
+using namespace lhost;
+
+namespace lh {
+__global__ __launch_bounds__(64) void k_seq_sum(const float *x, size_t n, float *out)
+{
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    for (size_t base = 0; base < n; base += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const size_t idx = base + (size_t)j * 64 + lane;
+            v[j] = idx < n ? x[idx] : 0.0f;  // acc + 0.0f == acc
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 64; i++)
+                acc = acc + __shfl(v[j], i, 64);
+    }
+    if (lane == 0)
+        out[0] = acc;
+}
+
+// ---- powf probe: out[i] = powf_glibc(bits-to-float(first + i), y) (tests: device powf == host libm, exhaustively)
+__global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_bits, size_t n, float y, int regular)
+{
+    __shared__ PowfTablesWide s_pw;
+    stage_powf_tables(&s_pw);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first_bits + (uint32_t)i);
+        float r;
+        if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
+            bool slow = false;
+            r = powf_regular<true, true, true>(x, y, s_pw, slow);
+            if (slow)
+                r = powf_glibc(x, y, s_pw);
+        } else {
+            r = powf_glibc(x, y, s_pw);
+        }
+        out[i] = r;
+    }
+}
+
+// ---- synthetic frames --------------------------------------------------------------
+LH_DEV uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_synth(float *dst, size_t frame_stride, int nframes, size_t n3, uint64_t seed,
+                                                uint64_t first_frame)
+{
+    const size_t total = n3 * nframes;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n3, j = i - f * n3;  // j = ch*h*w + idx
+        const uint64_t h64 = splitmix64(seed ^ ((first_frame + f) * 0x9E3779B97F4A7C15ull) ^ (uint64_t)j);
+        const uint32_t e = 117u + (uint32_t)((h64 >> 40) % 24u);
+        const uint32_t bits = (e << 23) + (uint32_t)(h64 & 0x7FE000u);
+        dst[f * frame_stride + j] = __uint_as_float(bits);
+    }
+}
+
+}  // namespace lh
+
+typedef void (*xf_kernel_t)(const XfArgs);
+static xf_kernel_t pick_xf(int cs, bool fwd)
+{
+    switch (cs) {
+    case CS_LUV: return fwd ? k_transform<CS_LUV, true> : k_transform<CS_LUV, false>;
+    case CS_RGB: return fwd ? k_transform<CS_RGB, true> : k_transform<CS_RGB, false>;
+    case CS_YCBCR: return fwd ? k_transform<CS_YCBCR, true> : k_transform<CS_YCBCR, false>;
+    case CS_XYZ: return fwd ? k_transform<CS_XYZ, true> : k_transform<CS_XYZ, false>;
+    }
+    return nullptr;
+}
+
+extern "C" int lumahip_transform_color_space_device(lumahip_ctx *c, float *frames, size_t frame_stride, unsigned nframes,
+                                                    unsigned w, unsigned h, int toCs, float sc)
+{
+    if (!c || !frames || nframes == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    if (w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "empty frame");
+    if (c->q.cs < 0 || c->q.cs > 3)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Error! Unrecognized color transformation");
+    const size_t n = (size_t)w * h;
+    if ((n & 1) || !is_aligned(frames, 8) || (frame_stride & 1))
+        return fail(c, LUMAHIP_ERR_ARG, "transform needs an even pixel count and 8-byte aligned frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    XfArgs a{};
+    a.buf = frames;
+    a.frame_stride = frame_stride;
+    a.chan_stride = n;
+    a.n2 = n / 2;
+    a.nframes = (int)nframes;
+    a.sc = sc;
+    a.Lmax = c->q.Lmax;
+    xf_kernel_t kern = pick_xf(c->q.cs, toCs != 0);
+    size_t total = a.n2 * nframes;
+    long grid = (long)((total + 255) / 256);
+    const long cap = (long)c->num_cu * 8;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_synth_frames_device(lumahip_ctx *c, float *dst, size_t frame_stride, unsigned nframes, unsigned w,
+                                           unsigned h, uint64_t seed, uint64_t first_frame)
+{
+    if (!c || !dst || nframes == 0 || w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n3 = (size_t)3 * w * h;
+    size_t total = n3 * nframes;
+    long grid = (long)((total + 255) / 256);
+    const long cap = (long)c->num_cu * 16;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)grid), dim3(256), 0, c->stream, dst, frame_stride, (int)nframes, n3, seed,
+                       first_frame);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const float *rgb, size_t frame_stride,
+                                     unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                                     unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                                     float *avg_ms)
+{
+    if (!c || iters <= 0 || !avg_ms)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ev;
+    HIPCHK(c, ev.create());
+    int rc = LUMAHIP_OK;
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    for (int i = 0; i < iters && rc == LUMAHIP_OK; i++) {
+        if (dir == 0)
+            rc = lumahip_encode_frames_device(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, nullptr);
+        else
+            rc = lumahip_decode_frames_device(c, (const unsigned char *const *)planes, stride, pfs, nframes, w, h, profile,
+                                              sc, const_cast<float *>(rgb), frame_stride);
+    }
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    *avg_ms = ms / iters;
+    return rc;
+}
+
+namespace lhost {
+
+// sequential fp32 sum of n device floats / (w*h), as the reference forms its mean luminance (see k_seq_sum)
+int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned h, float *mean_host)
+{
+    const size_t n = (size_t)w * h;
+    if (!c->d_stats)
+        HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, c->stream, chan0_dev, n, c->d_stats);
+    HIPCHK(c, hipGetLastError());
+    float sum = 0.0f;
+    int rc = read_small(c, &sum, c->d_stats, 1, c->stream);
+    if (rc)
+        return rc;
+    *mean_host = sum / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
+    return LUMAHIP_OK;
+}
+
+// mean of transformed channel 0 of ONE device-resident (untransformed) frame, summed exactly as the reference does
+int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc, int cs_eff,
+                                         float *mean_host)
+{
+    const size_t n = (size_t)w * h;
+    int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, n * sizeof(float));
+    if (rc)
+        return rc;
+    void (*kern)(const float *, size_t, size_t, float, float, float *) = nullptr;
+    switch (cs_eff) {
+    case CS_LUV: kern = k_channel0<CS_LUV>; break;
+    case CS_RGB: kern = k_channel0<CS_RGB>; break;
+    case CS_YCBCR: kern = k_channel0<CS_YCBCR>; break;
+    case CS_XYZ: kern = k_channel0<CS_XYZ>; break;
+    case CS_PACK: kern = k_channel0<CS_PACK>; break;
+    }
+    if (!kern)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", cs_eff);
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, rgb_dev, n, n, sc, c->q.Lmax, c->d_arr);
+    return seq_mean(c, c->d_arr, w, h, mean_host);
+}
+
+}  // namespace lhost
+
+extern "C" int lumahip_mean_luminance_reference_device(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc,
+                                                       float *mean_host)
+{
+    if (!c || !rgb_dev || !mean_host || w == 0 || h == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    return mean_luminance_reference_impl(c, rgb_dev, w, h, sc, c->q.cs, mean_host);
+}
+
+extern "C" int lumahip_powf_probe_device(lumahip_ctx *c, float *out_dev, uint32_t first_bits, size_t n, float y, int regular)
+{
+    if (!c || !out_dev || n == 0)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    long grid = (long)((n + 255) / 256);
+    if (grid > (long)c->num_cu * 16)
+        grid = (long)c->num_cu * 16;
+    hipLaunchKernelGGL(k_powf_probe, dim3((unsigned)grid), dim3(256), 0, c->stream, out_dev, first_bits, n, y, regular);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}
+
