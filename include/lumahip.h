@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LUMAHIP_ABI_VERSION 1
+#define LUMAHIP_ABI_VERSION 2
 
 enum lumahip_status {
     LUMAHIP_OK = 0,
@@ -60,6 +60,7 @@ int lumahip_device_count(int *count);
 int lumahip_create(lumahip_ctx **out, int device);
 void lumahip_destroy(lumahip_ctx *ctx);
 const char *lumahip_last_error(const lumahip_ctx *ctx);
+int lumahip_device(const lumahip_ctx *ctx);   /* the HIP ordinal the context is bound to */
 /* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead of the context's own
  * non-blocking stream.  NULL is a valid handle and means the device's default (null) stream -- which is what
  * PyTorch's default stream is.  lumahip_reset_stream goes back to the context's own stream. */
@@ -67,13 +68,27 @@ int lumahip_set_stream(lumahip_ctx *ctx, void *hip_stream);
 int lumahip_reset_stream(lumahip_ctx *ctx);
 int lumahip_sync(lumahip_ctx *ctx);
 
+/* Measurement overrides, none of which changes a result.  Keys: "block" (threads per workgroup: 64..1024, 0 = rule),
+ * "blocks_per_cu" (persistent workgroups per CU, 0 = rule), "grid_enc" / "grid_dec" (absolute workgroup count of the
+ * encode / decode launches, 0 = rule), "lds_table_max_kb" (largest search table staged in LDS, default 144, -1 = default),
+ * "force_literal" (1: the reference's bisection, src/luma_quantizer.cpp:222-235, run literally instead of the threshold
+ * records), "allow_aliased_frames" (1: the layout check accepts batches whose frames overlap), "lanes" (default lane
+ * count of lumahip_begin_unordered), "lane_grid_enc" / "lane_grid_dec" (workgroups per launch inside an unordered section,
+ * 0 = rule), "copy_threads" (worker threads that copy pageable caller memory into the pinned staging chunks of the _host
+ * entry points: 0..32, default 4).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
+ * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
+ * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS set the
+ * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
+int lumahip_tune(lumahip_ctx *ctx, const char *key, long value);
+
 /* ---- quantizer --------------------------------------------------------------------------------- */
 
 /* Replaces LumaQuantizer::setQuantizer (src/luma_quantizer.cpp:172-212) for the device side.  The host
  * facade builds the LUT exactly as the reference does (libm powf/log10f or the PSI/HDR-VDP tables) and,
  * on the decoder, overwrites its first getSize() entries with MKV attachment 434
  * (src/luma_decoder.cpp:121-122); the FINAL table of 2^bitdepth floats is handed over here.
- * bitdepth 1..16, bitdepthC 1..16.  The call uploads the LUT and builds the search index. */
+ * bitdepth 1..16, bitdepthC 1..16.  The call uploads the table; the encode-side search index is built (or taken from a
+ * process-wide cache keyed by the table) by the first encode-side call, so a context that only decodes never builds it. */
 int lumahip_set_quantizer(lumahip_ctx *ctx, int ptf, unsigned bitdepth, int colorspace, unsigned bitdepthC,
                           float maxLum, float minLum, const float *lut_host, size_t lut_len);
 
@@ -157,6 +172,34 @@ int lumahip_encode_frames_device(lumahip_ctx *ctx, const float *rgb_dev, size_t 
 int lumahip_decode_frames_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
                                  const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
                                  int profile, float sc, float *rgb_dev, size_t frame_stride);
+/* The same two calls for float frames given as three colour-plane base pointers: plane c of frame f at
+ * rgb_planes_dev[c] + f*frame_stride floats.  The LumaFrame layout of the calls above (include/luma/luma_frame.h:84-87:
+ * channel c at buffer + c*h*w) is the special case rgb_planes_dev[c] = rgb_dev + c*w*h, frame_stride >= 3*w*h.  Any layout in
+ * which no two planes overlap is accepted, e.g. all R planes of a batch in one buffer, all G planes in a second, all B planes
+ * in a third (frame_stride = w*h).  Why: the decode kernel writes 12 of its 15 bytes per pixel, and on MI355X three write
+ * streams in three HBM region groups (lumahip_pool below) run up to 11 % faster than one.  Results are
+ * identical to the packed calls. */
+int lumahip_encode_frames_device_planar(lumahip_ctx *ctx, const float *const rgb_planes_dev[3], size_t frame_stride,
+                                        unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                                        unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], float *stats_dev);
+int lumahip_decode_frames_device_planar(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
+                                        int profile, float sc, float *const rgb_planes_dev[3], size_t frame_stride);
+
+/* Unordered section.  Frames -- and therefore batches of frames -- are independent in this path (the quantizer is
+ * read-only state, src/luma_quantizer.cpp:215-264,267-482 keep nothing between frames), so a caller with several batches to
+ * process need not order them against each other.  Between lumahip_begin_unordered and lumahip_end_unordered the four
+ * _device encode / decode entry points above hand successive calls round-robin to `lanes` internal streams (1..4, 0 = the
+ * default of 3), each launch with a share of the persistent workgroups: one batch's ramp-up and tail overlap its neighbours'
+ * steady state (+4 % encode, +7 % decode on 20-frame 4K batches).  Ordering guarantees: everything enqueued on the context's
+ * stream before `begin` happens before every call of the section; everything enqueued after `end` happens after all of
+ * them; calls inside the section that went to the same lane run in call order; nothing else is promised, so the calls of
+ * one section must not depend on each other's output or write the same memory.  lumahip_sync inside a section waits for
+ * its lanes too.  All other entry points keep using the context's stream. */
+int lumahip_begin_unordered(lumahip_ctx *ctx, int lanes);
+int lumahip_end_unordered(lumahip_ctx *ctx);
+
 /* Decode fused with the display-side transform of the reference's player (the step on the far side of the decode
  * path: src/lumaplay_dequantizer.frag:145-156 -- exposure, optional 8-bit LDR simulation, optional sigmoid tone
  * curve n = sig = 0.8, display gamma) into RGBA8 (4 B/pixel, rows rgba_stride bytes apart, alpha 255).
@@ -221,11 +264,93 @@ int lumahip_probe_encode_traffic_device(lumahip_ctx *ctx, const float *rgb_dev, 
                                         unsigned w, unsigned h, unsigned char *const planes_dev[3], const int stride[3],
                                         const size_t plane_frame_stride[3], int iters, float *avg_ms);
 
+/* The decode counterpart: the loads and stores of the 4:2:0 16-bit decode kernel (3 B read + 12 B written per pixel) with no
+ * arithmetic.  OVERWRITES the frames with garbage.  Float frames as in lumahip_decode_frames_device_planar. */
+int lumahip_probe_decode_traffic_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
+                                        float *const rgb_planes_dev[3], size_t frame_stride, int iters, float *avg_ms);
+
 /* ---- device memory helpers (for hosts without their own allocator, e.g. the C++ facade) -------- */
 int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
 int lumahip_free(lumahip_ctx *ctx, void *dev_ptr);
 int lumahip_memcpy_h2d(lumahip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int lumahip_memcpy_d2h(lumahip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- HBM chunk pool: WHERE device-resident streams live ------------------------------------------------------------
+ * On MI355X device memory falls into a few groups of multi-GiB regions, and a launch runs up to 15 % slower when the
+ * stream it reads and the streams it writes meet in one group.  A resident-stream application owns its
+ * buffers for a long time, so it can look first: the pool takes device memory in chunks, finds the groups with traffic-only
+ * launches (lumahip_probe_encode_traffic_device), keeps n_y chunks of one group for Y planes, n_uv chunks of another for
+ * U / V planes, the n_float chunks that run fastest against those for float frames and, for channel-strided decode output,
+ * n_striped further chunks from EACH of the first three groups, and gives the rest back to the driver.  Nothing here touches results:
+ * the pool decides addresses only.  `ctx` must have a quantizer set and is used for the probes during creation only. */
+typedef struct lumahip_pool lumahip_pool;
+enum lumahip_pool_kind { LUMAHIP_POOL_FLOAT = 0, LUMAHIP_POOL_Y = 1, LUMAHIP_POOL_UV = 2, LUMAHIP_POOL_STRIPED = 3 };
+typedef struct lumahip_pool_config {
+    size_t chunk_bytes;      /* 0 = 2 GiB */
+    int n_float, n_y, n_uv;  /* chunks wanted of each kind */
+    int n_striped;           /* chunks wanted per group for LUMAHIP_POOL_STRIPED (0 = none) */
+    size_t keep_free_bytes;  /* device memory left untouched while probing (0 = 6 GiB) */
+    int max_chunks;          /* upper bound on the chunks taken for probing (0 = whatever is free) */
+    int probe_iters;         /* launches per probe (0 = 2) */
+} lumahip_pool_config;
+int lumahip_pool_create(lumahip_ctx *ctx, const lumahip_pool_config *cfg, lumahip_pool **out);
+void lumahip_pool_destroy(lumahip_pool *pool);   /* frees every chunk, handed out or not */
+/* One whole chunk of `kind` (fastest first).  group: -1 = any; for LUMAHIP_POOL_STRIPED the region group (0, 1, 2) the chunk
+ * must come from.  LUMAHIP_ERR_STATE when none is left. */
+int lumahip_pool_alloc(lumahip_pool *pool, int kind, int group, void **chunk_dev);
+int lumahip_pool_release(lumahip_pool *pool, void *chunk_dev);
+/* number of chunks of `kind` (and group, -1 = any) still available */
+int lumahip_pool_available(const lumahip_pool *pool, int kind, int group);
+/* region group of a chunk handed out by this pool (-1: not grouped / unknown) */
+int lumahip_pool_group_of(const lumahip_pool *pool, const void *chunk_dev);
+/* what the pool measured, as one JSON object (chunk count, group sizes, probe times, whether grouping was found);
+ * the string lives as long as the pool */
+const char *lumahip_pool_stats_json(const lumahip_pool *pool);
+/* Host-only (no GPU): the pool's grouping step with a caller-supplied measurement, probe(i, r, user) = time of a launch that
+ * reads chunk i while writing chunk r.  group_of[i] receives chunk i's group, *ngroups the number of groups (0 when the first
+ * round shows no contrast), *fastest (nullable) the fastest pair time seen, *nprobes (nullable) how often probe was called. */
+int lumahip_pool_find_groups(int n, double (*probe)(int i, int r, void *user), void *user, int *group_of, int *ngroups,
+                             double *fastest, int *nprobes);
+
+/* ---- many GPUs in one process ------------------------------------------------------------------------------------------
+ * Replaces the reference's frame loop `for (...) encoder.encode(&frame)` (lumaenc.cpp:205-243; lumadec.cpp:112-160 for
+ * decode) for callers that hold a batch of frames: the batch is split into contiguous blocks, one per shard (shard i gets
+ * frames lumahip_shard_range(n, i, nshards), the first n % nshards shards one frame more -- block, not round-robin, so each
+ * shard's output is already in stream order for the sequential VP9 consumer, src/luma_encoder.cpp:229-257), every shard has
+ * its own lumahip_ctx on its GPU and its own host thread, and no data-path communication.  The quantizer is built ONCE on
+ * the host and reaches the other GPUs by an RCCL broadcast (ncclCommInitAll + ncclBroadcast over xGMI) from the first
+ * device.  `devices` may name a device several times (several shards, i.e. several contexts and streams, on one GPU).
+ * Results are identical to a single context processing the frames in order. */
+typedef struct lumahip_multi lumahip_multi;
+int lumahip_multi_create(lumahip_multi **out, const int *devices, int nshards);   /* devices NULL: all visible devices */
+void lumahip_multi_destroy(lumahip_multi *m);
+int lumahip_multi_shards(const lumahip_multi *m);
+lumahip_ctx *lumahip_multi_ctx(lumahip_multi *m, int shard);   /* the shard's context (owned by m) */
+const char *lumahip_multi_last_error(const lumahip_multi *m);
+/* 1 when the table reached the devices through RCCL, 0 when only one distinct device is in use (nothing to broadcast) */
+int lumahip_multi_used_rccl(const lumahip_multi *m);
+int lumahip_shard_range(unsigned nframes, int shard, int nshards, unsigned *first, unsigned *count);
+/* same arguments as lumahip_set_quantizer; the table is uploaded to the first device and broadcast to the others */
+int lumahip_multi_set_quantizer(lumahip_multi *m, int ptf, unsigned bitdepth, int colorspace, unsigned bitdepthC,
+                                float maxLum, float minLum, const float *lut_host, size_t lut_len);
+/* same arguments and results as lumahip_encode_frames_host / lumahip_decode_frames_host */
+int lumahip_multi_encode_frames_host(lumahip_multi *m, const float *const *rgb, unsigned nframes, unsigned w, unsigned h,
+                                     float sc, int profile, unsigned char *const *planes, const int stride[3],
+                                     float *mean_lum);
+int lumahip_multi_decode_frames_host(lumahip_multi *m, const unsigned char *const *planes, const int stride[3],
+                                     unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const *rgb_out);
+/* Device-resident form: shard i's block of `count[i]` frames lives on shard i's GPU at rgb_dev[i] (frames frame_stride floats
+ * apart) with planes at planes_dev[3*i + p] (plane_frame_stride[p] bytes apart).  Enqueues one batched launch per shard
+ * (asynchronous); lumahip_multi_sync waits for all shards. */
+int lumahip_multi_encode_frames_device(lumahip_multi *m, const float *const *rgb_dev, size_t frame_stride,
+                                       const unsigned *count, unsigned w, unsigned h, float sc, int profile,
+                                       unsigned char *const *planes_dev, const int stride[3],
+                                       const size_t plane_frame_stride[3]);
+int lumahip_multi_decode_frames_device(lumahip_multi *m, const unsigned char *const *planes_dev, const int stride[3],
+                                       const size_t plane_frame_stride[3], const unsigned *count, unsigned w, unsigned h,
+                                       int profile, float sc, float *const *rgb_dev, size_t frame_stride);
+int lumahip_multi_sync(lumahip_multi *m);
 
 #ifdef __cplusplus
 }

@@ -20,13 +20,23 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device", "lumahip_mean_luminance_reference_device",
     "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
+    "lumahip_device", "lumahip_encode_frames_device_planar", "lumahip_decode_frames_device_planar", "lumahip_begin_unordered", "lumahip_end_unordered",
+    "lumahip_probe_decode_traffic_device",
+    "lumahip_pool_create", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
+    "lumahip_pool_stats_json", "lumahip_pool_find_groups",
+    "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl",
+    "lumahip_shard_range", "lumahip_multi_set_quantizer", "lumahip_multi_encode_frames_host", "lumahip_multi_decode_frames_host",
+    "lumahip_multi_encode_frames_device", "lumahip_multi_decode_frames_device", "lumahip_multi_sync",
     "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_quantize_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
+
+
+PROBE_FN = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int, C.c_void_p)
 
 
 class LumaHipError(RuntimeError):
@@ -103,6 +113,7 @@ def lib():
     L.lumahip_set_stream.argtypes = [vp, vp]
     L.lumahip_reset_stream.argtypes = [vp]
     L.lumahip_sync.argtypes = [vp]
+    L.lumahip_tune.argtypes = [vp, C.c_char_p, C.c_long]
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
     L.lumahip_thresh_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
@@ -134,8 +145,71 @@ def lib():
     L.lumahip_free.argtypes = [vp, vp]
     L.lumahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.lumahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.lumahip_device.argtypes = [vp]
+    L.lumahip_encode_frames_device_planar.argtypes = [vp, pp3, sz, u, u, u, f, i, pp3, ip3, sp3, vp]
+    L.lumahip_decode_frames_device_planar.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, pp3, sz]
+    L.lumahip_begin_unordered.argtypes = [vp, i]
+    L.lumahip_end_unordered.argtypes = [vp]
+    L.lumahip_probe_decode_traffic_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, pp3, sz, i, C.POINTER(f)]
+    L.lumahip_pool_create.argtypes = [vp, C.POINTER(PoolConfig), C.POINTER(vp)]
+    L.lumahip_pool_destroy.argtypes = [vp]
+    L.lumahip_pool_destroy.restype = None
+    L.lumahip_pool_alloc.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.lumahip_pool_release.argtypes = [vp, vp]
+    L.lumahip_pool_available.argtypes = [vp, i, i]
+    L.lumahip_pool_group_of.argtypes = [vp, vp]
+    L.lumahip_pool_stats_json.argtypes = [vp]
+    L.lumahip_pool_stats_json.restype = C.c_char_p
+    L.lumahip_pool_find_groups.argtypes = [i, PROBE_FN, vp, vp, C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i)]
+    L.lumahip_multi_create.argtypes = [C.POINTER(vp), ip3, i]
+    L.lumahip_multi_destroy.argtypes = [vp]
+    L.lumahip_multi_destroy.restype = None
+    L.lumahip_multi_shards.argtypes = [vp]
+    L.lumahip_multi_ctx.argtypes = [vp, i]
+    L.lumahip_multi_ctx.restype = vp
+    L.lumahip_multi_last_error.argtypes = [vp]
+    L.lumahip_multi_last_error.restype = C.c_char_p
+    L.lumahip_multi_used_rccl.argtypes = [vp]
+    L.lumahip_shard_range.argtypes = [u, i, i, C.POINTER(u), C.POINTER(u)]
+    L.lumahip_multi_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
+    L.lumahip_multi_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
+    L.lumahip_multi_decode_frames_host.argtypes = [vp, pp3, ip3, u, u, u, i, f, pp3]
+    L.lumahip_multi_encode_frames_device.argtypes = [vp, pp3, sz, C.POINTER(u), u, u, f, i, pp3, ip3, sp3]
+    L.lumahip_multi_decode_frames_device.argtypes = [vp, pp3, ip3, sp3, C.POINTER(u), u, u, i, f, pp3, sz]
+    L.lumahip_multi_sync.argtypes = [vp]
     _lib = L
     return L
+
+
+class PoolConfig(C.Structure):
+    """lumahip_pool_config (include/lumahip.h)"""
+    _fields_ = [("chunk_bytes", C.c_size_t), ("n_float", C.c_int), ("n_y", C.c_int), ("n_uv", C.c_int), ("n_striped", C.c_int),
+                ("keep_free_bytes", C.c_size_t), ("max_chunks", C.c_int), ("probe_iters", C.c_int)]
+
+
+POOL_FLOAT, POOL_Y, POOL_UV, POOL_STRIPED = range(4)
+
+
+def shard_range(nframes: int, shard: int, nshards: int) -> range:
+    """lumahip_shard_range: the contiguous block of frames shard `shard` of `nshards` owns"""
+    a, b = C.c_uint(0), C.c_uint(0)
+    rc = lib().lumahip_shard_range(nframes, shard, nshards, C.byref(a), C.byref(b))
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_shard_range(%d, %d, %d)" % (nframes, shard, nshards))
+    return range(a.value, a.value + b.value)
+
+
+def pool_find_groups(n: int, probe):
+    """host-only: the chunk pool's grouping step (lumahip_pool_find_groups) with a Python measurement probe(i, r) -> time of
+    reading chunk i while writing chunk r.  Returns (groups or None when there is no contrast, fastest pair time, probes)."""
+    g = np.full(n, -1, dtype=np.int32)
+    ng, npr, fast = C.c_int(0), C.c_int(0), C.c_double(0.0)
+    cb = PROBE_FN(lambda i, r, _u: float(probe(i, r)))
+    rc = lib().lumahip_pool_find_groups(n, cb, None, g.ctypes.data, C.byref(ng), C.byref(fast), C.byref(npr))
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_pool_find_groups failed")
+    groups = None if ng.value == 0 else [[int(i) for i in np.nonzero(g == k)[0]] for k in range(ng.value)]
+    return groups, fast.value, npr.value
 
 
 def plane_geometry(w: int, h: int, profile: int, align: int = 32):
@@ -225,6 +299,10 @@ class Context:
 
     def sync(self):
         self._chk(self.L.lumahip_sync(self.h))
+
+    def tune(self, key: str, value: int):
+        """measurement override (include/lumahip.h lumahip_tune); never changes a result"""
+        self._chk(self.L.lumahip_tune(self.h, key.encode(), int(value)))
 
     def set_quantizer(self, ptf, bitdepth, cs, bitdepthC, max_lum, min_lum, lut: np.ndarray):
         lut = np.ascontiguousarray(lut, dtype=np.float32)
@@ -373,6 +451,38 @@ class Context:
                                                _arr3(C.c_size_t, plane_frame_strides), C.byref(ms)))
         return float(ms.value)
 
+    def device(self) -> int:
+        return int(self.L.lumahip_device(self.h))
+
+    def encode_frames_device_planar(self, rgb_plane_ptrs, frame_stride, nframes, w, h, sc, profile, plane_ptrs, strides,
+                                    plane_frame_strides, stats_ptr=None):
+        """float frames as three colour-plane base pointers (plane c of frame f at rgb_plane_ptrs[c] + f*frame_stride floats)"""
+        self._chk(self.L.lumahip_encode_frames_device_planar(self.h, _arr3(C.c_void_p, rgb_plane_ptrs), frame_stride, nframes, w, h,
+                                                             sc, profile, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                             _arr3(C.c_size_t, plane_frame_strides), stats_ptr))
+
+    def decode_frames_device_planar(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, profile, sc, rgb_plane_ptrs,
+                                    frame_stride):
+        self._chk(self.L.lumahip_decode_frames_device_planar(self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                             _arr3(C.c_size_t, plane_frame_strides), nframes, w, h, profile, sc,
+                                                             _arr3(C.c_void_p, rgb_plane_ptrs), frame_stride))
+
+    def begin_unordered(self, lanes: int = 0):
+        """open an unordered section: the following _device encode / decode calls are independent of each other"""
+        self._chk(self.L.lumahip_begin_unordered(self.h, lanes))
+
+    def end_unordered(self):
+        self._chk(self.L.lumahip_end_unordered(self.h))
+
+    def probe_decode_traffic(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, rgb_plane_ptrs, frame_stride,
+                             iters=1) -> float:
+        """ms per launch of the decode kernel's loads + stores without arithmetic (overwrites the frames)"""
+        ms = C.c_float(0)
+        self._chk(self.L.lumahip_probe_decode_traffic_device(self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                             _arr3(C.c_size_t, plane_frame_strides), nframes, w, h,
+                                                             _arr3(C.c_void_p, rgb_plane_ptrs), frame_stride, iters, C.byref(ms)))
+        return float(ms.value)
+
     def probe_encode_traffic(self, rgb_ptr, frame_stride, nframes, w, h, plane_ptrs, strides, plane_frame_strides,
                              iters=1) -> float:
         """ms per launch of the encode kernel's loads + stores without arithmetic (overwrites the planes)"""
@@ -412,3 +522,153 @@ class Context:
     def d2h(self, arr: np.ndarray, src_ptr):
         assert arr.flags.c_contiguous
         self._chk(self.L.lumahip_memcpy_d2h(self.h, arr.ctypes.data, src_ptr, arr.nbytes))
+
+
+class Pool:
+    """lumahip_pool: device memory in chunks, classified by HBM region group (include/lumahip.h)"""
+
+    def __init__(self, ctx: Context, n_float, n_y, n_uv, n_striped=0, chunk_bytes=0, keep_free=0, max_chunks=0, iters=0):
+        self.L = lib()
+        cfg = PoolConfig(chunk_bytes, n_float, n_y, n_uv, n_striped, keep_free, max_chunks, iters)
+        h = C.c_void_p()
+        rc = self.L.lumahip_pool_create(ctx.h, C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_pool_create failed")
+        self.h = h
+        self.chunk_bytes = chunk_bytes or (2 << 30)
+
+    def stats(self) -> dict:
+        import json
+        return json.loads(self.L.lumahip_pool_stats_json(self.h).decode())
+
+    def available(self, kind, group=-1) -> int:
+        return int(self.L.lumahip_pool_available(self.h, kind, group))
+
+    def alloc(self, kind, group=-1) -> int:
+        p = C.c_void_p()
+        rc = self.L.lumahip_pool_alloc(self.h, kind, group, C.byref(p))
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_pool_alloc: no chunk of kind %d / group %d left" % (kind, group))
+        return p.value
+
+    def release(self, ptr: int):
+        rc = self.L.lumahip_pool_release(self.h, C.c_void_p(ptr))
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_pool_release: not a chunk of this pool")
+
+    def group_of(self, ptr: int) -> int:
+        return int(self.L.lumahip_pool_group_of(self.h, C.c_void_p(ptr)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lumahip_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """lumahip_multi: one context per shard, block-sharded batches, quantizer broadcast over RCCL (include/lumahip.h)"""
+
+    def __init__(self, devices=None, nshards=0):
+        self.L = lib()
+        h = C.c_void_p()
+        if devices is None:
+            rc = self.L.lumahip_multi_create(C.byref(h), None, nshards)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.L.lumahip_multi_create(C.byref(h), arr, len(devices))
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_multi_create failed (there is no CPU fallback)")
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise LumaHipError(rc, self.L.lumahip_multi_last_error(self.h).decode())
+
+    @property
+    def shards(self) -> int:
+        return int(self.L.lumahip_multi_shards(self.h))
+
+    def used_rccl(self) -> bool:
+        return bool(self.L.lumahip_multi_used_rccl(self.h))
+
+    def ctx(self, shard: int) -> Context:
+        """the shard's context as a (non-owning) Context"""
+        raw = self.L.lumahip_multi_ctx(self.h, shard)
+        if not raw:
+            raise LumaHipError(ERR_ARG, "no such shard")
+        return _BorrowedContext(self.L, C.c_void_p(raw))
+
+    def set_quantizer(self, ptf, bitdepth, cs, bitdepthC, max_lum, min_lum, lut: np.ndarray):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        self._chk(self.L.lumahip_multi_set_quantizer(self.h, ptf, bitdepth, cs, bitdepthC, max_lum, min_lum, lut.ctypes.data,
+                                                     lut.size))
+
+    def encode_frames(self, frames, sc=1.0, profile=2, align=32):
+        frames = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+        n = len(frames)
+        _, h, w = frames[0].shape
+        _, hs, st, _ = plane_geometry(w, h, profile, align)
+        planes = [[np.zeros((hs[p], st[p]), dtype=np.uint8) for p in range(3)] for _ in range(n)]
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        pp = (C.c_void_p * (3 * n))(*[pl.ctypes.data for tri in planes for pl in tri])
+        means = (C.c_float * n)()
+        self._chk(self.L.lumahip_multi_encode_frames_host(self.h, fp, n, w, h, sc, profile, pp, _arr3(C.c_int, st), means))
+        return planes, st, [float(m) for m in means]
+
+    def decode_frames(self, planes_list, strides, w, h, sc=1.0, profile=2):
+        n = len(planes_list)
+        planes_list = [[np.ascontiguousarray(p) for p in tri] for tri in planes_list]
+        outs = [np.empty((3, h, w), dtype=np.float32) for _ in range(n)]
+        pp = (C.c_void_p * (3 * n))(*[pl.ctypes.data for tri in planes_list for pl in tri])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self._chk(self.L.lumahip_multi_decode_frames_host(self.h, pp, _arr3(C.c_int, strides), n, w, h, profile, sc, op))
+        return outs
+
+    def encode_frames_device(self, rgb_ptrs, frame_stride, counts, w, h, sc, profile, plane_ptrs, strides, plane_frame_strides):
+        """rgb_ptrs[s], counts[s], plane_ptrs[s] = (Y, U, V) per shard"""
+        ns = self.shards
+        rp = (C.c_void_p * ns)(*rgb_ptrs)
+        cn = (C.c_uint * ns)(*counts)
+        pp = (C.c_void_p * (3 * ns))(*[p for tri in plane_ptrs for p in tri])
+        self._chk(self.L.lumahip_multi_encode_frames_device(self.h, rp, frame_stride, cn, w, h, sc, profile, pp,
+                                                            _arr3(C.c_int, strides), _arr3(C.c_size_t, plane_frame_strides)))
+
+    def decode_frames_device(self, plane_ptrs, strides, plane_frame_strides, counts, w, h, profile, sc, rgb_ptrs, frame_stride):
+        ns = self.shards
+        rp = (C.c_void_p * ns)(*rgb_ptrs)
+        cn = (C.c_uint * ns)(*counts)
+        pp = (C.c_void_p * (3 * ns))(*[p for tri in plane_ptrs for p in tri])
+        self._chk(self.L.lumahip_multi_decode_frames_device(self.h, pp, _arr3(C.c_int, strides),
+                                                            _arr3(C.c_size_t, plane_frame_strides), cn, w, h, profile, sc, rp,
+                                                            frame_stride))
+
+    def sync(self):
+        self._chk(self.L.lumahip_multi_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lumahip_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BorrowedContext(Context):
+    """a Context view of a lumahip_ctx owned by someone else (a Multi): never destroyed from here"""
+
+    def __init__(self, L, h):
+        self.L = L
+        self.h = h
+
+    def close(self):
+        self.h = None

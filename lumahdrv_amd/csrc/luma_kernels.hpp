@@ -38,7 +38,8 @@ struct FrameGeom {
 struct EncArgs {
     QuantDev q;
     FrameGeom g;
-    const float *src;     // frame f at src + f*frame_stride; channel c at + c*w*h
+    const float *src[3];  // colour plane c of frame f at src[c] + f*frame_stride (the reference's LumaFrame,
+                          // include/luma/luma_frame.h:84-87 there, is src[c] = base + c*w*h, frame_stride = 3*w*h)
     size_t frame_stride;  // floats
     unsigned char *dst[3];
     int stride[3];        // bytes
@@ -55,7 +56,7 @@ struct DecArgs {
     const unsigned char *src[3];
     int stride[3];
     size_t src_frame_stride[3];
-    float *dst;           // nullable when only the display output is wanted
+    float *dst[3];        // colour plane c of frame f at dst[c] + f*frame_stride; dst[0] null when only the display output is wanted
     size_t frame_stride;
     float sc;
     int bps;
@@ -276,7 +277,7 @@ struct EncUnit {
 };
 
 template <int VW>
-LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, int NW, size_t cs)
+LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, int NW)
 {
     u.valid = false;
     if (t >= a.g.totalTiles)
@@ -288,11 +289,11 @@ LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, in
     if (u.ux >= a.g.unitsX || u.uy >= a.g.unitsY)
         return;
     u.valid = true;
-    const float *p = a.src + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+    const size_t off = (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        load_px<VW>(p + c * cs, u.in[c][0]);
-        load_px<VW>(p + c * cs + a.g.w, u.in[c][1]);
+        load_px<VW>(a.src[c] + off, u.in[c][0]);
+        load_px<VW>(a.src[c] + off + a.g.w, u.in[c][1]);
     }
 }
 
@@ -457,7 +458,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t cs = (size_t)a.g.w * a.g.h;  // channel stride (floats)
     const int G = gridDim.x;
 
     EncStats st;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     // before the stores (round 1) measured 1.0-1.3 % slower HBM-fed, same-box, 5 of 5 interleaved rounds: with the
     // stores first the write bursts of a wave are not queued behind its own 6 KiB of reads.
     EncUnit<VW> u;
-    enc_load<VW>(u, a, blockIdx.x, tx, ty, NW, cs);
+    enc_load<VW>(u, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
         if (a.stats) {
             const int f = t / a.g.tilesPerFrame;  // wave-uniform
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
             else
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_rec);
         }
-        enc_load<VW>(u, a, t + G, tx, ty, NW, cs);
+        enc_load<VW>(u, a, t + G, tx, ty, NW);
     }
     if (a.stats)
         stats_flush(st, a.stats, tx);
@@ -558,7 +558,7 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
 }
 
 template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, typename LutPtr>
-LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, const float *s_uv, size_t cs)
+LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, const float *s_uv)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
     const float maxC = a.q.maxC;
@@ -638,12 +638,12 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
                     out[c][r][i] = div_ieee(out[c][r][i], k.sc);
     }
 
-    if (!DISP || a.dst) {
-        float *p = a.dst + (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+    if (!DISP || a.dst[0]) {
+        const size_t off = (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            store_px<VW>(p + c * cs, out[c][0]);
-            store_px<VW>(p + c * cs + a.g.w, out[c][1]);
+            store_px<VW>(a.dst[c] + off, out[c][0]);
+            store_px<VW>(a.dst[c] + off + a.g.w, out[c][1]);
         }
     }
     if constexpr (DISP) {
@@ -699,7 +699,6 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t cs = (size_t)a.g.w * a.g.h;
     const int G = gridDim.x;
 
     DecUnit<SUB, VW> cur, nxt;
@@ -707,9 +706,9 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
         if (cur.valid) {
             if constexpr (GL)
-                dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv, cs);
+                dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
             else
-                dec_process<CS, SUB, VW, DISP, UVTAB>(cur, a, k, s_lut, s_uv, cs);
+                dec_process<CS, SUB, VW, DISP, UVTAB>(cur, a, k, s_lut, s_uv);
         }
         // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
         // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)

@@ -57,25 +57,20 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         c->num_cu = prop.multiProcessorCount;
-    if (const char *e = getenv("LUMAHIP_BLOCK")) {
-        int v = atoi(e);
-        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
-            c->block_threads = v;
-            c->block_forced = true;
-        }
-    }
-    if (const char *e = getenv("LUMAHIP_BLOCKS_PER_CU"))
-        c->blocks_per_cu = atoi(e);
-    if (const char *e = getenv("LUMAHIP_GRID_ENC"))
-        c->grid_override[0] = atol(e);
-    if (const char *e = getenv("LUMAHIP_GRID_DEC"))
-        c->grid_override[1] = atol(e);
-    if (const char *e = getenv("LUMAHIP_ALLOW_ALIASED_FRAMES"))
-        c->allow_alias = atoi(e) != 0;
-    if (const char *e = getenv("LUMAHIP_LDS_TABLE_MAX_KB")) {
-        const long kb = atol(e);
-        if (kb >= 0 && kb <= 152)
-            c->lds_table_max = (size_t)kb * 1024;
+    // Measurement overrides (launch geometry, LDS limit, literal search) are lumahip_tune() calls; the LUMAHIP_* environment
+    // variables of the same names are honoured only under LUMAHIP_TUNING=1, so that a stray variable cannot change how a
+    // production process launches.
+    if (const char *g = getenv("LUMAHIP_TUNING"); g && atoi(g) != 0) {
+        static const char *const keys[][2] = {{"LUMAHIP_BLOCK", "block"}, {"LUMAHIP_BLOCKS_PER_CU", "blocks_per_cu"},
+                                              {"LUMAHIP_GRID_ENC", "grid_enc"}, {"LUMAHIP_GRID_DEC", "grid_dec"},
+                                              {"LUMAHIP_ALLOW_ALIASED_FRAMES", "allow_aliased_frames"},
+                                              {"LUMAHIP_LDS_TABLE_MAX_KB", "lds_table_max_kb"},
+                                              {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
+                                              {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
+                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}};
+        for (const auto &k : keys)
+            if (const char *e = getenv(k[0]))
+                (void)lumahip_tune(c, k[1], atol(e));
     }
     *out = c;
     return LUMAHIP_OK;
@@ -108,9 +103,15 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
         if (st->ev) (void)hipEventDestroy(st->ev);
     }
     if (c->h_small) (void)hipHostFree(c->h_small);
+    lumahip_copy_pool_destroy(c->copy_pool);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_kern) (void)hipStreamDestroy(c->s_kern);
     if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    for (int i = 0; i < LUMAHIP_MAX_LANES; i++) {
+        if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
+        if (c->lane_done[i]) (void)hipEventDestroy(c->lane_done[i]);
+    }
+    if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -118,10 +119,14 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
 
 extern "C" const char *lumahip_last_error(const lumahip_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+extern "C" int lumahip_device(const lumahip_ctx *c) { return c ? c->device : -1; }
+
 extern "C" int lumahip_set_stream(lumahip_ctx *c, void *s)
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
+    if (c->lanes_active)
+        return fail(c, LUMAHIP_ERR_STATE, "close the unordered section before changing the stream");
     c->stream = (hipStream_t)s;  // NULL is a valid handle: the device's default (null) stream
     return LUMAHIP_OK;
 }
@@ -143,7 +148,217 @@ extern "C" int lumahip_sync(lumahip_ctx *c)
     return LUMAHIP_OK;
 }
 
+// ---- unordered sections ------------------------------------------------------------------------------------------
+// One long launch leaves the memory system under-used while it ramps up (table staging, the first loads) and while its
+// last workgroups finish; back-to-back launches on one stream pay that at every boundary.  Batches of frames are
+// independent, so inside a section successive launches go to different streams and one batch's ramp / tail overlaps its
+// neighbours' steady state (profiles/r02_concurrent_launches.txt: +4 % encode, +7 % decode).
+extern "C" int lumahip_begin_unordered(lumahip_ctx *c, int lanes)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (c->lanes_active)
+        return fail(c, LUMAHIP_ERR_STATE, "lumahip_begin_unordered: a section is already open");
+    if (lanes == 0)
+        lanes = c->lanes_default > 0 ? c->lanes_default : 3;
+    if (lanes < 1 || lanes > LUMAHIP_MAX_LANES)
+        return fail(c, LUMAHIP_ERR_ARG, "lanes must be 1..%d (0 = default)", LUMAHIP_MAX_LANES);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->lane_fork)
+        HIPCHK(c, hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+    for (int i = 0; i < lanes; i++) {
+        if (!c->lane_stream[i]) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming));
+        }
+    }
+    // everything queued on the context's stream so far happens before the section
+    HIPCHK(c, hipEventRecord(c->lane_fork, c->stream));
+    for (int i = 0; i < lanes; i++)
+        HIPCHK(c, hipStreamWaitEvent(c->lane_stream[i], c->lane_fork, 0));
+    c->lanes_active = lanes;
+    c->lane_next = 0;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_end_unordered(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!c->lanes_active)
+        return fail(c, LUMAHIP_ERR_STATE, "lumahip_end_unordered: no section is open");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int lanes = c->lanes_active;
+    c->lanes_active = 0;
+    // everything queued on the context's stream from now on happens after the section
+    for (int i = 0; i < lanes; i++) {
+        HIPCHK(c, hipEventRecord(c->lane_done[i], c->lane_stream[i]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[i], 0));
+    }
+    return LUMAHIP_OK;
+}
+
+static int requantize(lumahip_ctx *c);
+
+extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
+{
+    if (!c || !key)
+        return LUMAHIP_ERR_ARG;
+    const std::string k(key);
+    if (k == "block") {
+        if (v == 0) {
+            c->block_threads = 256;
+            c->block_forced = false;
+        } else if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
+            c->block_threads = (int)v;
+            c->block_forced = true;
+        } else {
+            return fail(c, LUMAHIP_ERR_ARG, "block must be 0 (default), 64, 128, 256, 512 or 1024");
+        }
+    } else if (k == "blocks_per_cu") {
+        c->blocks_per_cu = v > 0 ? (int)v : 0;
+    } else if (k == "grid_enc") {
+        c->grid_override[0] = v > 0 ? v : 0;
+    } else if (k == "grid_dec") {
+        c->grid_override[1] = v > 0 ? v : 0;
+    } else if (k == "allow_aliased_frames") {
+        c->allow_alias = v != 0;
+    } else if (k == "lds_table_max_kb") {
+        if (v < 0)
+            c->lds_table_max = LUMAHIP_LDS_TABLE_MAX_DEFAULT;
+        else if (v <= 152)
+            c->lds_table_max = (size_t)v * 1024;
+        else
+            return fail(c, LUMAHIP_ERR_ARG, "lds_table_max_kb must be 0..152 (or -1 for the default)");
+        if (c->have_quant)
+            return requantize(c);
+    } else if (k == "force_literal") {
+        c->force_literal = v != 0;
+        if (c->have_quant)
+            return requantize(c);
+    } else if (k == "copy_threads") {
+        if (v < 0 || v > 32)
+            return fail(c, LUMAHIP_ERR_ARG, "copy_threads must be 0..32");
+        lumahip_copy_pool_destroy(c->copy_pool);
+        c->copy_pool = nullptr;
+        c->copy_threads = (int)v;
+    } else if (k == "lane_grid_enc") {
+        c->lane_grid[0] = v > 0 ? v : 0;
+    } else if (k == "lane_grid_dec") {
+        c->lane_grid[1] = v > 0 ? v : 0;
+    } else if (k == "lanes") {
+        if (v < 0 || v > LUMAHIP_MAX_LANES)
+            return fail(c, LUMAHIP_ERR_ARG, "lanes must be 0..%d", LUMAHIP_MAX_LANES);
+        c->lanes_default = (int)v;
+    } else {
+        return fail(c, LUMAHIP_ERR_ARG, "unknown tuning key '%s'", key);
+    }
+    return LUMAHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------- quantizer
+
+// The search index of a table is a pure function of the table, and several contexts of one process usually hold the same
+// table (one per GPU in the multi-device layer, encoder + decoder of a transcoder): built once, shared.
+namespace {
+struct IndexCacheEntry {
+    std::vector<float> lut;
+    std::shared_ptr<const ThreshIndex> ix;
+};
+std::mutex g_index_mutex;
+std::vector<IndexCacheEntry> g_index_cache;  // a handful of entries, most recent last
+
+std::shared_ptr<const ThreshIndex> cached_thresh_index(const std::vector<float> &lut)
+{
+    std::lock_guard<std::mutex> lk(g_index_mutex);
+    for (auto &e : g_index_cache)
+        if (e.lut.size() == lut.size() && memcmp(e.lut.data(), lut.data(), lut.size() * sizeof(float)) == 0)
+            return e.ix;
+    IndexCacheEntry e;
+    e.lut = lut;
+    e.ix = std::make_shared<const ThreshIndex>(build_thresh_index(lut.data(), (int)lut.size(), 1 << 19));
+    if (g_index_cache.size() >= 8)
+        g_index_cache.erase(g_index_cache.begin());
+    g_index_cache.push_back(e);
+    return e.ix;
+}
+}  // namespace
+
+// device copy of the table + the decode-side decisions: everything a decoder needs
+static int upload_table(lumahip_ctx *c)
+{
+    const size_t n = c->h_lut.size();
+    const size_t powf_b = (c->q.cs == CS_YCBCR) ? sizeof(PowfTablesWide) : 0;
+    // decode side: luminance table (+ Lu'v' chroma table, + the powf tables for YCbCr) staged in LDS
+    c->lut_in_lds = c->bitdepthC <= 12 && (n + 4) * sizeof(float) <= std::max<size_t>(c->lds_table_max, 16 * 1024 + 16) &&
+                    (n + 4) * sizeof(float) + ((size_t)4 << c->bitdepthC) + 64 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP;
+    const size_t lut_floats = (n + 1 + 3) & ~(size_t)3;  // NaN padding up to a multiple of 16 bytes
+    std::vector<float> padded(lut_floats, __builtin_nanf(""));
+    memcpy(padded.data(), c->h_lut.data(), n * sizeof(float));
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_rec);
+    c->d_lut = nullptr;
+    c->d_rec = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
+    QuantDev &q = c->q;
+    q.lut = c->d_lut;
+    q.rec = nullptr;
+    q.lut_len = (int)n;
+    q.pad = (int)(lut_floats - n);
+    q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
+    q.mode = n <= 4096 ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
+    q.shift = q.kmin = q.nbuckets = 0;
+    c->tix.reset();
+    c->index_ready = false;
+    return LUMAHIP_OK;
+}
+
+// The encode-side search index, built (or fetched from the cache) when the first encode-side launch needs it: a context
+// that only decodes never pays for it (for a 16-bit table it is tens of millions of host table probes).
+// Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit lds_table_max, else in global
+// memory (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table) runs
+// the reference's bisection literally; so does everything after lumahip_tune(ctx, "force_literal", 1) (the tests' hook).
+int lhost::ensure_search_index(lumahip_ctx *c)
+{
+    if (c->index_ready)
+        return LUMAHIP_OK;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set (call lumahip_set_quantizer first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    QuantDev &q = c->q;
+    if (!c->force_literal) {
+        c->tix = cached_thresh_index(c->h_lut);
+        if (c->tix->ok) {
+            const size_t powf_b = (q.cs == CS_YCBCR) ? sizeof(PowfTablesWide) : 0;
+            const ThreshIndex &ix = *c->tix;
+            std::vector<uint32_t> r((ix.rec.size() + 3) & ~(size_t)3, 0u);
+            memcpy(r.data(), ix.rec.data(), ix.rec.size() * sizeof(uint32_t));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_rec);
+            c->d_rec = nullptr;
+            HIPCHK(c, hipMalloc(&c->d_rec, r.size() * sizeof(uint32_t)));
+            HIPCHK(c, hipMemcpy(c->d_rec, r.data(), r.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            q.rec = c->d_rec;
+            q.mode = (ix.rec.size() * 4 <= c->lds_table_max && ix.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP)
+                         ? LUT_THRESH_LDS
+                         : LUT_THRESH_GLOBAL;
+            q.shift = ix.shift;
+            q.kmin = ix.kmin;
+            q.nbuckets = ix.nbuckets;
+        }
+    }
+    c->index_ready = true;
+    return LUMAHIP_OK;
+}
+
+// after a tuning change that moves a table between LDS and global memory / switches the search
+static int requantize(lumahip_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return upload_table(c);
+}
 
 extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth, int cs, unsigned bitdepthC,
                                      float maxLum, float minLum, const float *lut, size_t n)
@@ -160,56 +375,18 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-
-    // Search index.  Every monotone finite table gets threshold records (lut_index.hpp): in LDS when they fit
-    // lds_table_max, else in global memory
-    // (L2-resident).  Anything else (NaNs, decreasing entries -- a decoder may be handed any attachment-434 table)
-    // runs the reference's bisection literally.  LUMAHIP_FORCE_LITERAL is the tests' hook for that path.
-    c->tix = ThreshIndex();
-    // decode side: luminance table (+ Lu'v' chroma table, + the powf tables for YCbCr) staged in LDS
-    const size_t powf_b = (cs == CS_YCBCR) ? sizeof(PowfTablesWide) : 0;
-    c->lut_in_lds = bitdepthC <= 12 && (n + 4) * sizeof(float) <= std::max<size_t>(c->lds_table_max, 16 * 1024 + 16) &&
-                    (n + 4) * sizeof(float) + ((size_t)4 << bitdepthC) + 64 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP;
-    int mode = n <= 4096 ? LUT_LITERAL_LDS : LUT_LITERAL_GLOBAL;
-    if (!getenv("LUMAHIP_FORCE_LITERAL")) {
-        c->tix = build_thresh_index(lut, (int)n, 1 << 19);
-        if (c->tix.ok)
-            mode = (c->tix.rec.size() * 4 <= c->lds_table_max && c->tix.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP)
-                       ? LUT_THRESH_LDS
-                       : LUT_THRESH_GLOBAL;
-    }
-    const size_t lut_floats = (n + 1 + 3) & ~(size_t)3;  // NaN padding up to a multiple of 16 bytes
-    std::vector<float> padded(lut_floats, __builtin_nanf(""));
-    memcpy(padded.data(), lut, n * sizeof(float));
-    (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_rec);
-    c->d_lut = nullptr;
-    c->d_rec = nullptr;
-    HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
-    HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
-    if (c->tix.ok) {
-        std::vector<uint32_t> r((c->tix.rec.size() + 3) & ~(size_t)3, 0u);
-        memcpy(r.data(), c->tix.rec.data(), c->tix.rec.size() * sizeof(uint32_t));
-        HIPCHK(c, hipMalloc(&c->d_rec, r.size() * sizeof(uint32_t)));
-        HIPCHK(c, hipMemcpy(c->d_rec, r.data(), r.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    QuantDev &q = c->q;
-    q.lut = c->d_lut;
-    q.rec = c->d_rec;
-    q.lut_len = (int)n;
-    q.pad = (int)(lut_floats - n);
-    q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
-    q.mode = mode;
-    q.shift = c->tix.ok ? c->tix.shift : 0;
-    q.kmin = c->tix.ok ? c->tix.kmin : 0;
-    q.nbuckets = c->tix.ok ? c->tix.nbuckets : 0;
-    q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);        // src/luma_quantizer.cpp:183
-    q.cs = cs;
-    q.Lmax = maxLum;
+    c->have_quant = false;
+    c->h_lut.assign(lut, lut + n);
+    c->q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);     // src/luma_quantizer.cpp:183
+    c->q.cs = cs;
+    c->q.Lmax = maxLum;
     c->ptf = ptf;
     c->bitdepth = bitdepth;
     c->bitdepthC = bitdepthC;
     c->minLum = minLum;
+    const int rc = upload_table(c);
+    if (rc)
+        return rc;
     c->have_quant = true;
     return LUMAHIP_OK;
 }
@@ -239,10 +416,15 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
         return LUMAHIP_ERR_ARG;
     if (!c->have_quant)
         return LUMAHIP_ERR_STATE;
+    lumahip_ctx *m = const_cast<lumahip_ctx *>(c);  // builds the (lazily built) search index if nothing has yet
+    const int rc = ensure_search_index(m);
+    if (rc)
+        return rc;
+    const bool ok = c->tix && c->tix->ok;
     info[0] = c->q.mode;
-    info[1] = c->tix.ok ? c->tix.mant_bits : 0;
+    info[1] = ok ? c->tix->mant_bits : 0;
     info[2] = c->q.nbuckets;
-    info[3] = c->tix.ok ? c->tix.shift : 0;
+    info[3] = ok ? c->tix->shift : 0;
     info[4] = (int)lds_bytes(c, true, c->q.cs);
     return LUMAHIP_OK;
 }
@@ -345,6 +527,17 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool f
     if (ycbcr && c->blocks_per_cu == 0 && threads == 512 && total_tiles >= 8L * c->num_cu * 18)
         per_cu = dir == 0 ? 18 : 12;
     long g = (long)c->num_cu * per_cu;
+    // Inside an unordered section `lanes_active` launches share the chip: each gets a share of the workgroups one launch
+    // would have -- more than 1/lanes of them, so that the chip stays full while a lane is between two launches
+    // (3 lanes: 4 per CU each for encode against 3 alone, 2.5 per CU each for decode against 5; r02_concurrent_launches.txt)
+    if (c->lanes_active > 1 && c->blocks_per_cu == 0 && threads == 256 && !ycbcr) {
+        if (c->lane_grid[dir] > 0)
+            g = c->lane_grid[dir];
+        else if (dir == 0 && per_cu == 3)
+            g = (long)c->num_cu * 12 / c->lanes_active;
+        else if (dir == 1 && per_cu == 5)
+            g = (long)c->num_cu * 15 / (2 * c->lanes_active);
+    }
     if (c->grid_override[dir] > 0)
         g = c->grid_override[dir];
     if (g > total_tiles)
@@ -355,6 +548,13 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool f
 }
 
 // rows and bytes per row of plane p as vpx_img_alloc lays it out (src/luma_encoder.cpp:121-128)
+hipStream_t launch_stream(lumahip_ctx *c)
+{
+    if (c->lanes_active == 0)
+        return c->stream;
+    return c->lane_stream[c->lane_next++ % (unsigned)c->lanes_active];
+}
+
 void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes)
 {
     const bool sub = (profile == 0 || profile == 2);
@@ -365,8 +565,8 @@ void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_
 
 // the device entry points take caller-chosen strides: reject layouts in which rows or frames would overlap or the
 // kernels would write outside a plane (negative / too small strides, frame strides smaller than a frame)
-int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, size_t frame_stride,
-                        const int stride[3], const size_t pfs[3])
+int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, const float *const rgb[3],
+                 size_t frame_stride, const int stride[3], const size_t pfs[3])
 {
     for (int p = 0; p < 3; p++) {
         int rows, row_bytes;
@@ -376,8 +576,26 @@ int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned n
         if (nframes > 1 && !c->allow_alias && pfs[p] < (size_t)rows * (size_t)stride[p])
             return fail(c, LUMAHIP_ERR_ARG, "plane %d: frame stride %zu < plane size %zu", p, pfs[p], (size_t)rows * stride[p]);
     }
-    if (nframes > 1 && !c->allow_alias && frame_stride < (size_t)3 * w * h)
-        return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < 3*w*h = %zu floats", frame_stride, (size_t)3 * w * h);
+    if (!rgb || c->allow_alias)
+        return LUMAHIP_OK;
+    // float frames: colour plane k of frame f covers [rgb[k] + f*frame_stride, + w*h).  No two of the 3*nframes planes may
+    // overlap.  Plane sequence k is the arithmetic progression rgb[k] + f*frame_stride; two sequences are fine when they are
+    // disjoint as whole ranges (channel-major layouts) or when they interleave with room for each other inside one frame
+    // stride (frame-major layouts, the reference's LumaFrame among them).
+    const size_t n = (size_t)w * h;
+    if (nframes > 1 && frame_stride < n)
+        return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < w*h = %zu floats", frame_stride, n);
+    const size_t span = (size_t)(nframes - 1) * frame_stride + n;  // floats one plane sequence covers
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++) {
+            const float *lo = rgb[i] < rgb[j] ? rgb[i] : rgb[j], *hi = rgb[i] < rgb[j] ? rgb[j] : rgb[i];
+            const size_t d = (size_t)(hi - lo);
+            const bool disjoint = d >= span;
+            const bool interleaved = d >= n && (nframes == 1 || d + n <= frame_stride);
+            if (!disjoint && !interleaved)
+                return fail(c, LUMAHIP_ERR_ARG, "colour planes %d and %d (%zu floats apart, frame stride %zu): planes of different "
+                                                 "frames would overlap", i, j, d, frame_stride);
+        }
     return LUMAHIP_OK;
 }
 

@@ -93,23 +93,27 @@ static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp)
 namespace lhost {
 
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
-                       unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
-                       const DisplayParams &dp, int cs_eff)
+                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
+                const DisplayParams &dp, int cs_eff)
 {
-    if (!c || (!rgb && !dp.rgba) || !planes || !stride || !pfs || nframes == 0)
+    const bool have_rgb = rgb && rgb[0];
+    if (!c || (!have_rgb && !dp.rgba) || (have_rgb && (!rgb[1] || !rgb[2])) || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
-    if ((rc = check_layout(c, w, h, profile, nframes, rgb ? frame_stride : (size_t)3 * w * h, stride, pfs)))
+    if ((rc = check_layout(c, w, h, profile, nframes, have_rgb ? rgb : nullptr, frame_stride, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
     const bool gl = !c->lut_in_lds;
-    int vw = (!gl && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
-    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
-        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    float *const none[3] = {nullptr, nullptr, nullptr};
+    float *const *out = have_rgb ? rgb : none;
+    const bool al16 = is_aligned(out[0], 16) && is_aligned(out[1], 16) && is_aligned(out[2], 16);
+    int vw = (!gl && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(out[0], 8) || !is_aligned(out[1], 8) || !is_aligned(out[2], 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
     if (dp.rgba && (!is_aligned(dp.rgba, 4) || (dp.stride % 4) != 0 || (dp.frame_stride % 4) != 0 || dp.stride < (int)(4 * w)))
         return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
     DecArgs a{};
@@ -118,7 +122,8 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
-    a.dst = rgb;
+    for (int k = 0; k < 3; k++)
+        a.dst[k] = out[k];
     a.frame_stride = frame_stride;
     a.sc = sc;
     a.bps = bps;
@@ -154,6 +159,9 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
 int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    if (quant)
+        if (int rc = ensure_search_index(c))
+            return rc;
     QArrArgs a{};
     a.q = c->q;
     a.in = d_in;
@@ -193,7 +201,98 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     if (!c)
         return LUMAHIP_ERR_ARG;
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb, frame_stride, DisplayParams(), c->q.cs);
+    const size_t n = (size_t)w * h;
+    float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, DisplayParams(), c->q.cs);
+}
+
+extern "C" int lumahip_decode_frames_device_planar(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                                   const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                                   float sc, float *const rgb_planes[3], size_t frame_stride)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!rgb_planes || !rgb_planes[0])
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_planes, frame_stride, DisplayParams(), c->q.cs);
+}
+
+// Traffic probe: the loads and stores of k_decode<., 4:2:0, VW=4> for 16-bit planes with NO arithmetic (an xor keeps every
+// loaded word live): 3 B read + 12 B written per pixel, same tile order, same software pipeline (the next unit's sample
+// loads go out after the current unit's stores), same non-temporal accesses.  Its run time is what the memory system alone
+// needs for the decode traffic mix; bench.py reports the decode kernel's time as a fraction of it.
+namespace lh {
+__global__ __launch_bounds__(256) void k_decode_traffic_probe(const DecArgs a)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const int G = gridDim.x;
+    DecUnit<true, 4> cur, nxt;
+    dec_load<true, 4>(cur, a, blockIdx.x, tx, ty, NW);
+    for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
+        if (cur.valid) {
+            const size_t off = (size_t)cur.f * a.frame_stride + (size_t)(2 * cur.uy) * a.g.w + (size_t)cur.ux * 4;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int k = c == 0 ? 0 : (c == 1 ? cur.c1[0] ^ cur.c1[1] : cur.c2[0] ^ cur.c2[1]);
+                float r0[4], r1[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    r0[i] = __int_as_float(cur.y[0][i] ^ k);
+                    r1[i] = __int_as_float(cur.y[1][i] ^ k);
+                }
+                store_px<4>(a.dst[c] + off, r0);
+                store_px<4>(a.dst[c] + off + a.g.w, r1);
+            }
+        }
+        dec_load<true, 4>(nxt, a, t + G, tx, ty, NW);
+        cur = nxt;
+    }
+}
+}  // namespace lh
+
+extern "C" int lumahip_probe_decode_traffic_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                                   const size_t pfs[3], unsigned nframes, unsigned w, unsigned h,
+                                                   float *const rgb_planes[3], size_t frame_stride, int iters, float *avg_ms)
+{
+    if (!c || !rgb_planes || !planes || !stride || !pfs || nframes == 0 || iters <= 0 || !avg_ms)
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (w == 0 || h == 0 || (w % 4) || (h & 1) || (frame_stride % 4))
+        return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs w %% 4 == 0, even h and 16-byte aligned frames");
+    for (int k = 0; k < 3; k++)
+        if (!rgb_planes[k] || !is_aligned(rgb_planes[k], 16))
+            return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs 16-byte aligned colour planes");
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || !is_aligned(planes[p], 8) || (stride[p] % (p ? 4 : 8)) || (pfs[p] % 8))
+            return fail(c, LUMAHIP_ERR_ARG, "the traffic probe needs 8-byte aligned 16-bit 4:2:0 planes");
+    HIPCHK(c, hipSetDevice(c->device));
+    DecArgs a{};
+    const int threads = 256;
+    if (!make_geom(a.g, w, h, 4, threads / 64, nframes))
+        return fail(c, LUMAHIP_ERR_ARG, "batch too large");
+    for (int k = 0; k < 3; k++)
+        a.dst[k] = rgb_planes[k];
+    a.frame_stride = frame_stride;
+    a.bps = 2;
+    a.aligned = 1;
+    for (int p = 0; p < 3; p++) {
+        a.src[p] = planes[p];
+        a.stride[p] = stride[p];
+        a.src_frame_stride[p] = pfs[p];
+    }
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, true, false);
+    EventPair ev;
+    HIPCHK(c, ev.create());
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_decode_traffic_probe, dim3(grid), dim3(threads), 0, c->stream, a);
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    HIPCHK(c, hipGetLastError());
+    *avg_ms = ms / iters;
+    return LUMAHIP_OK;
 }
 
 extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsigned char *const planes[3],
@@ -215,7 +314,9 @@ extern "C" int lumahip_decode_display_frames_device(lumahip_ctx *c, const unsign
     dp.gamma = gamma;
     dp.do_tmo = do_tmo;
     dp.ldr_sim = ldr_sim;
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_or_null, frame_stride, dp, c->q.cs);
+    const size_t n = (size_t)w * h;
+    float *const pl[3] = {rgb_or_null, rgb_or_null ? rgb_or_null + n : nullptr, rgb_or_null ? rgb_or_null + 2 * n : nullptr};
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, dp, c->q.cs);
 }
 
 extern "C" int lumahip_quantize_array_device(lumahip_ctx *c, const float *in_dev, float *out_dev, size_t n, unsigned ch)

@@ -14,21 +14,20 @@ __global__ __launch_bounds__(256) void k_encode_traffic_probe(const EncArgs a)
 {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t cs = (size_t)a.g.w * a.g.h;
     for (int t = blockIdx.x; t < a.g.totalTiles; t += gridDim.x) {
         int f, bx, by;
         tile_coords(t, a.g, f, bx, by);
         const int ux = bx * 64 + tx, uy = by * NW + ty;
         if (ux >= a.g.unitsX || uy >= a.g.unitsY)
             continue;
-        const float *p = a.src + (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * 4;
+        const size_t off = (size_t)f * a.frame_stride + (size_t)(2 * uy) * a.g.w + (size_t)ux * 4;
         uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 float v[4];
-                load_px<4>(p + c * cs + (size_t)r * a.g.w, v);
+                load_px<4>(a.src[c] + off + (size_t)r * a.g.w, v);
                 q0 ^= __float_as_uint(v[0]); q1 ^= __float_as_uint(v[1]); q2 ^= __float_as_uint(v[2]); q3 ^= __float_as_uint(v[3]);
             }
         unsigned char *d0 = a.dst[0] + (size_t)f * a.dst_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * 8;
@@ -79,25 +78,28 @@ __global__ void k_init_stats(float *s, int nframes)
 
 namespace lhost {
 
-int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w,
-                                     unsigned h, float sc, int profile, unsigned char *const planes[3], const int stride[3],
-                                     const size_t pfs[3], float *stats, int cs_eff)
+int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
+                              unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff)
 {
-    if (!c || !rgb || !planes || !stride || !pfs || nframes == 0)
+    if (!c || !rgb || !rgb[0] || !rgb[1] || !rgb[2] || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
-    if ((rc = check_layout(c, w, h, profile, nframes, frame_stride, stride, pfs)))
+    if ((rc = check_layout(c, w, h, profile, nframes, rgb, frame_stride, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_search_index(c)))
+        return rc;
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
     const int mode = c->q.mode;
     const bool fast_search = (mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
-    int vw = (fast_search && (w % 4) == 0 && is_aligned(rgb, 16) && (frame_stride % 4) == 0) ? 4 : 2;
-    if (!is_aligned(rgb, 8) || (frame_stride % 2) != 0)
-        return fail(c, LUMAHIP_ERR_ARG, "frame base must be 8-byte aligned and frame stride even");
+    const bool al16 = is_aligned(rgb[0], 16) && is_aligned(rgb[1], 16) && is_aligned(rgb[2], 16);
+    int vw = (fast_search && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
+    if (!is_aligned(rgb[0], 8) || !is_aligned(rgb[1], 8) || !is_aligned(rgb[2], 8) || (frame_stride % 2) != 0)
+        return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
     EncArgs a{};
     a.q = c->q;
     const size_t lds = lds_bytes(c, true, cs_eff);
@@ -105,7 +107,8 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_str
     const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
-    a.src = rgb;
+    for (int k = 0; k < 3; k++)
+        a.src[k] = rgb[k];
     a.frame_stride = frame_stride;
     a.sc = sc;
     a.bps = bps;
@@ -126,9 +129,10 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_str
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
+    hipStream_t s = launch_stream(c);
     if (stats)
-        hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, c->stream, stats, (int)nframes);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+        hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, s, stats, (int)nframes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }
@@ -142,7 +146,21 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
-    return encode_frames_device_impl(c, rgb, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+    if (!rgb)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    const size_t n = (size_t)w * h;
+    const float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
+    return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+}
+
+extern "C" int lumahip_encode_frames_device_planar(lumahip_ctx *c, const float *const rgb_planes[3], size_t frame_stride,
+                                                   unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                                                   unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                                                   float *stats)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    return encode_frames_device_impl(c, rgb_planes, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
 }
 
 extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,
@@ -161,7 +179,8 @@ extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *
     const int threads = 256;
     if (!make_geom(a.g, w, h, 4, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large");
-    a.src = rgb;
+    for (int k = 0; k < 3; k++)
+        a.src[k] = rgb + (size_t)k * w * h;
     a.frame_stride = frame_stride;
     a.bps = 2;
     a.aligned = 1;
@@ -192,6 +211,8 @@ extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, 
     if (!c->have_quant)
         return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_search_index(c))
+        return rc;
     const size_t lds = lds_bytes(c, true, CS_PACK);
     void (*kern)(const QuantDev, uint16_t *, uint32_t, size_t) = nullptr;
     switch (c->q.mode) {

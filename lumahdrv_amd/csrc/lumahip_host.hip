@@ -2,6 +2,9 @@
 // pipeline of the batched forms.  No kernels here.
 #include "lumahip_internal.hpp"
 
+#include <condition_variable>
+#include <thread>
+
 using namespace lh;
 using namespace lhost;
 
@@ -13,7 +16,121 @@ using namespace lhost;
 // allocated and freed at a high rate ("Memory access fault by GPU ... on address <host heap page>", about one run of
 // the GPU test suite in twenty).  Pageable data therefore moves through two context-owned pinned chunks per direction:
 // the CPU copy of chunk k+1 overlaps the DMA of chunk k.
-static constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+static constexpr size_t XFER_CHUNK = (size_t)16 << 20;
+
+// ---- copy threads ---------------------------------------------------------------------------------------------------------
+// One CPU thread copies pageable memory into a pinned chunk at ~21 GB/s on the GPU box's host, a third of what the PCIe
+// link moves (profiles/r02_hostfed.txt: 1.4 Gpixel/s pageable against 4.2 pinned).  The staging copies are therefore split
+// over a few persistent worker threads owned by the context (lumahip_tune "copy_threads", default 4; 0 = the calling thread
+// alone): the CPU side then keeps up with the DMA of the previous chunk.
+struct lumahip_copy_pool {
+    struct Job {
+        unsigned char *dst;
+        const unsigned char *src;
+        size_t width, rows, dst_pitch, src_pitch;  // rows x width bytes; rows == 1: one flat span
+    };
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<Job> jobs;     // one per worker for the current generation
+    unsigned generation = 0;
+    int pending = 0;
+    bool stop = false;
+
+    explicit lumahip_copy_pool(int n)
+    {
+        jobs.resize(n);
+        for (int i = 0; i < n; i++)
+            workers.emplace_back([this, i]() { loop(i); });
+    }
+    ~lumahip_copy_pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : workers)
+            t.join();
+    }
+    static void run(const Job &j)
+    {
+        if (j.rows == 1) {
+            memcpy(j.dst, j.src, j.width);
+        } else {
+            for (size_t r = 0; r < j.rows; r++)
+                memcpy(j.dst + r * j.dst_pitch, j.src + r * j.src_pitch, j.width);
+        }
+    }
+    void loop(int me)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || generation != seen; });
+                if (stop)
+                    return;
+                seen = generation;
+                j = jobs[me];
+            }
+            if (j.width)
+                run(j);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0)
+                    cv_done.notify_one();
+            }
+        }
+    }
+    // rows x width bytes from src (pitch sp) to dst (pitch dp), split over the workers and the calling thread
+    void copy(unsigned char *dst, size_t dp, const unsigned char *src, size_t sp, size_t width, size_t rows)
+    {
+        const size_t parts = workers.size() + 1;
+        const bool flat = rows == 1;
+        const size_t total = flat ? width : rows;
+        if (total * (flat ? 1 : width) < ((size_t)1 << 20) || total < parts) {  // small: not worth waking anyone
+            run(Job{dst, src, width, rows, dp, sp});
+            return;
+        }
+        // flat spans are cut at 4 KiB boundaries so that no two threads share a page
+        size_t per = (total + parts - 1) / parts;
+        if (flat)
+            per = (per + 4095) & ~(size_t)4095;
+        auto part = [&](size_t k) -> Job {
+            const size_t a = std::min(total, k * per), b = std::min(total, (k + 1) * per);
+            if (a >= b)
+                return Job{nullptr, nullptr, 0, 0, 0, 0};
+            return flat ? Job{dst + a, src + a, b - a, 1, 0, 0} : Job{dst + a * dp, src + a * sp, width, b - a, dp, sp};
+        };
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < workers.size(); k++)
+                jobs[k] = part(k + 1);
+            pending = (int)workers.size();
+            generation++;
+        }
+        cv_go.notify_all();
+        const Job mine = part(0);
+        if (mine.width)
+            run(mine);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+void lumahip_copy_pool_destroy(lumahip_copy_pool *p) { delete p; }
+
+static void staged_copy(lumahip_ctx *c, unsigned char *dst, size_t dp, const unsigned char *src, size_t sp, size_t width, size_t rows)
+{
+    if (c->copy_threads > 0 && !c->copy_pool)
+        c->copy_pool = new lumahip_copy_pool(c->copy_threads);
+    if (c->copy_pool)
+        c->copy_pool->copy(dst, dp, src, sp, width, rows);
+    else
+        lumahip_copy_pool::run(lumahip_copy_pool::Job{dst, src, width, rows, dp, sp});
+}
 
 static bool host_range_is_pinned(const void *p, size_t bytes)
 {
@@ -75,11 +192,10 @@ static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, si
         const size_t n = total - done < per ? total - done : per;
         size_t bytes;
         if (flat) {
-            memcpy(st.h, (const unsigned char *)src + done, n);
+            staged_copy(c, st.h, 0, (const unsigned char *)src + done, 0, n, 1);
             bytes = n;
         } else {
-            for (size_t r = 0; r < n; r++)
-                memcpy(st.h + r * dp, (const unsigned char *)src + (done + r) * hp, width);
+            staged_copy(c, st.h, dp, (const unsigned char *)src + done * hp, hp, width, n);
             bytes = (n - 1) * dp + width;
         }
         HIPCHK(c, hipMemcpyAsync((unsigned char *)dst + done * (flat ? 1 : dp), st.h, bytes, hipMemcpyHostToDevice, s));
@@ -122,12 +238,10 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
     auto drain = [&](lumahip_ctx::Stage &st, size_t at, size_t n) -> int {
         HIPCHK(c, hipEventSynchronize(st.ev));
         st.pending = false;
-        if (flat) {
-            memcpy((unsigned char *)dst + at, st.h, n);
-        } else {
-            for (size_t r = 0; r < n; r++)
-                memcpy((unsigned char *)dst + (at + r) * hp, st.h + r * dp, width);
-        }
+        if (flat)
+            staged_copy(c, (unsigned char *)dst + at, 0, st.h, 0, n, 1);
+        else
+            staged_copy(c, (unsigned char *)dst + at * hp, hp, st.h, dp, width, n);
         return LUMAHIP_OK;
     };
     for (size_t done = 0; done < total; k++) {
@@ -241,7 +355,10 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         return rc;
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
     const size_t pfs[3] = {0, 0, 0};
-    rc = encode_frames_device_impl(c, c->d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
+    {
+        const float *const fp[3] = {c->d_frame, c->d_frame + nfl / 3, c->d_frame + 2 * (nfl / 3)};
+        rc = encode_frames_device_impl(c, fp, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
+    }
     if (rc)
         return rc;
     for (int p = 0; p < 3; p++)
@@ -299,7 +416,10 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
         if ((rc = xfer_h2d_2d(c, dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
             return rc;
     const size_t pfs[3] = {0, 0, 0};
-    rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, c->d_frame, nfl, DisplayParams(), cs_eff);
+    {
+        float *const fp[3] = {c->d_frame, c->d_frame + nfl / 3, c->d_frame + 2 * (nfl / 3)};
+        rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, fp, nfl, DisplayParams(), cs_eff);
+    }
     if (rc)
         return rc;
     if ((rc = xfer_d2h(c, rgb_out, c->d_frame, nfl * sizeof(float), c->stream)))

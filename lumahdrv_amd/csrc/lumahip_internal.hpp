@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +30,10 @@
 // them from L2 (346 against 182 Gpixel/s, profiles/r02_perf_matrix.txt).  LUMAHIP_LDS_TABLE_MAX_KB overrides it.
 static constexpr size_t LUMAHIP_LDS_TABLE_MAX_DEFAULT = 144 * 1024;
 static constexpr size_t LUMAHIP_LDS_PER_WORKGROUP = 160 * 1024;
+static constexpr int LUMAHIP_MAX_LANES = 4;
+
+struct lumahip_copy_pool;                                   // lumahip_host.hip: worker threads of the staging copies
+void lumahip_copy_pool_destroy(lumahip_copy_pool *p);
 
 struct lumahip_ctx {
     int device = 0;
@@ -40,7 +46,10 @@ struct lumahip_ctx {
     int ptf = 0;
     unsigned bitdepth = 0, bitdepthC = 0;
     lh::QuantDev q{};
-    lh::ThreshIndex tix;
+    std::shared_ptr<const lh::ThreshIndex> tix;  // encode-side search index, built on first use (ensure_search_index)
+    bool index_ready = false;
+    bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
+    std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer
     float *d_lut = nullptr;
     uint32_t *d_rec = nullptr;
     bool lut_in_lds = true;  // decode side: tables up to 12 bits are staged in LDS
@@ -74,6 +83,8 @@ struct lumahip_ctx {
         bool pending = false;  // a DMA that reads / writes this chunk may still be in flight
     } stage_up[2], stage_dn[2];
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
+    lumahip_copy_pool *copy_pool = nullptr;
+    int copy_threads = 4;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)
 
     int block_threads = 256;
     bool block_forced = false;
@@ -81,6 +92,15 @@ struct lumahip_ctx {
     int blocks_per_cu = 0;  // 0 = occupancy query
     long grid_override[2] = {0, 0};
     size_t lds_table_max = LUMAHIP_LDS_TABLE_MAX_DEFAULT;
+    // Unordered sections (lumahip_begin_unordered): successive _device encode / decode calls go round-robin to `lanes_active`
+    // internal streams, so that one batch's ramp-up and tail overlap its neighbours' steady state
+    hipStream_t lane_stream[LUMAHIP_MAX_LANES] = {};
+    hipEvent_t lane_done[LUMAHIP_MAX_LANES] = {};
+    hipEvent_t lane_fork = nullptr;
+    int lanes_active = 0;
+    unsigned lane_next = 0;
+    long lane_grid[2] = {0, 0};   // lumahip_tune("lane_grid_enc" / "lane_grid_dec"): workgroups per launch inside a section
+    int lanes_default = 0;        // lumahip_tune("lanes"): lanes an unordered section opens with when asked for 0
 };
 
 int lumahip_fail(lumahip_ctx *c, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
@@ -125,22 +145,26 @@ struct DisplayParams {
 };
 
 // ---- lumahip_core.hip
+int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff);
 int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
 int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false);
+hipStream_t launch_stream(lumahip_ctx *c);   // the context's stream, or the next lane of an unordered section
 void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes);
-int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, size_t frame_stride,
-                 const int stride[3], const size_t pfs[3]);
+// rgb: the three colour-plane base pointers of the float frames (nullptr: no float frames in this call)
+int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, const float *const rgb[3],
+                 size_t frame_stride, const int stride[3], const size_t pfs[3]);
 
 // ---- lumahip_encode.hip / lumahip_decode.hip: cs_eff = the colour space the kernels run (the context's, or CS_PACK /
 // CS_RGB for the pack-only entry points)
-int encode_frames_device_impl(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w,
-                              unsigned h, float sc, int profile, unsigned char *const planes[3], const int stride[3],
-                              const size_t pfs[3], float *stats, int cs_eff);
+// rgb[c]: base of colour plane c; plane c of frame f at rgb[c] + f*frame_stride floats
+int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
+                              unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff);
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
-                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride,
+                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
                 const DisplayParams &dp, int cs_eff);
 int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant);
 

@@ -10,7 +10,7 @@
      c. quantize_lut<records, 4, NONNEG=true>, the instantiation the Lu'v' encode kernels call (they promise the
         search "v >= 0 or NaN"), over 0 .. 0x7fffffff = every non-negative float, +inf and every sign-clear NaN, plus
         every sign-set NaN 0xff800001 .. 0xffffffff.
-   The other side of each comparison is the literal bisection kernel on the GPU (LUMAHIP_FORCE_LITERAL), itself
+   The other side of each comparison is the literal bisection kernel on the GPU (lumahip_tune "force_literal"), itself
    pinned against the oracle / the reference fixtures in test_gpu_parity.py and spot-checked here against the oracle.
 2. The device powf (pow_glibc.hpp) equals the host libm powf for every non-negative float, for the four PQ exponents.
 3. The YCbCr decode kernel (8 straight-line powf per pixel with range arguments stated in luma_device.hpp) equals the
@@ -29,16 +29,12 @@ TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12),
 def _pair(L, ptf, bits, cs):
     """(records context, literal context) for the same table"""
     lut = L.build_lut(ptf, bits, 1e4, 0.005)
-    os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
     fast = L.Context(0)
     fast.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
     assert fast.quantizer_info()["mode"] in (3, 4)
-    os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
-    try:
-        lit = L.Context(0)
-        lit.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
-    finally:
-        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
+    lit = L.Context(0)
+    lit.tune("force_literal", 1)
+    lit.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
     assert lit.quantizer_info()["mode"] in (0, 2)
     return fast, lit
 
@@ -140,20 +136,14 @@ def test_global_memory_records_sampled(oracle_mod, ptf, bits):
     import lumahdrv_amd as L
     dev = torch.device("cuda:0")
     lut = L.build_lut(ptf, bits, 1e4, 0.005)
-    os.environ["LUMAHIP_LDS_TABLE_MAX_KB"] = "0"
-    try:
-        fast = L.Context(0)
-    finally:
-        os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
+    fast = L.Context(0)
+    fast.tune("lds_table_max_kb", 0)
     fast.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
     if fast.quantizer_info()["mode"] != 4:
         pytest.skip("table does not qualify for records (mode %d)" % fast.quantizer_info()["mode"])
-    os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
-    try:
-        lit = L.Context(0)
-        lit.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
-    finally:
-        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
+    lit = L.Context(0)
+    lit.tune("force_literal", 1)
+    lit.set_quantizer(ptf, bits, L.CS_LUV, 8, 1e4, 0.005, lut)
     assert lit.quantizer_info()["mode"] == 2
     s = torch.cuda.current_stream().cuda_stream
     fast.set_stream(s)

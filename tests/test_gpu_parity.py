@@ -175,16 +175,12 @@ def test_literal_and_global_lut_modes(L, oracle_mod):
     lut13 = L.build_lut(L.PTF_PQ, 13).copy()
     bad13 = lut13.copy()
     bad13[3000:3010] = bad13[3000:3010][::-1]
-    #     LUMAHIP_LDS_TABLE_MAX_KB moves the boundary: 64 -> records in global memory (mode 4), the decode kernels'
+    #     lumahip_tune("lds_table_max_kb") moves the boundary: 64 -> records in global memory (mode 4), the decode kernels'
     #     32 KiB luminance table still in LDS; 0 -> the decode kernels read theirs from global memory as well
-    for table, mode, kb in ((None, 3, None), (bad13, 2, None), (None, 4, "64"), (None, 4, "0")):
-        os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
+    for table, mode, kb in ((None, 3, None), (bad13, 2, None), (None, 4, 64), (None, 4, 0)):
+        q2 = L.LumaQuantizer()
         if kb is not None:
-            os.environ["LUMAHIP_LDS_TABLE_MAX_KB"] = kb
-        try:
-            q2 = L.LumaQuantizer()
-        finally:
-            os.environ.pop("LUMAHIP_LDS_TABLE_MAX_KB", None)
+            q2.ctx.tune("lds_table_max_kb", kb)
         q2.setQuantizer(L.PTF_PQ, 13, L.CS_XYZ, 8, 1e4, 0.005, mapping_override=table)
         assert q2.ctx.quantizer_info()["mode"] == mode
         orc2 = o.Oracle(o.PTF_PQ, 13, o.CS_XYZ, 8, 1e4, 0.005)

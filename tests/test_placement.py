@@ -1,5 +1,6 @@
-"""lumahdrv_amd/placement.py: the host logic of the HBM chunk pool (group finding, role choice, slot arithmetic) on
-synthetic timings -- CPU only; the pool itself is exercised on the GPU by tests/test_gpu_multi.py."""
+"""The host logic of the HBM chunk pool -- lumahip_pool_find_groups of the C ABI (lumahdrv_amd/csrc/lumahip_pool.hip) through
+lumahdrv_amd/placement.py, and the slot arithmetic -- on synthetic timings.  CPU only; the pool itself is exercised on the
+GPU by tests/test_gpu_placement.py."""
 import random
 
 from lumahdrv_amd.placement import CHUNK_BYTES, find_groups, plane_slots, slots

@@ -1,5 +1,6 @@
 #!/bin/bash
 # encode, 3 workgroups per CU (B: LUMAHIP_GRID_ENC=768) against the default 8 (A), same build, one process (tools/ab_inproc.py)
+export LUMAHIP_TUNING=1   # the LUMAHIP_* overrides are honoured only under this gate
 L=lumahdrv_amd/lib/liblumahip.so
 for cfg in "pq11_luv 2" "pq11_luv 3" "pq11_rgb 2" "pq11_rgb 3" "pq8_luv 0" "pq8_luv 1"; do
   set -- $cfg

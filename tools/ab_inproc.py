@@ -53,6 +53,7 @@ def main():
         # AB_ENV_A / AB_ENV_B = "NAME=value,NAME=value": environment switches read when that side's context is created
         extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + side, "").split(",") if "=" in kv)
         os.environ.update(extra)
+        os.environ["LUMAHIP_TUNING"] = "1"   # the LUMAHIP_* overrides are honoured only under this gate
         c = m.Context(0)
         for k in extra:
             os.environ.pop(k, None)

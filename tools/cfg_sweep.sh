@@ -1,5 +1,6 @@
 #!/bin/bash
 # bench.py (headline workload only, placement auto) under different launch configurations, round-robin twice
+export LUMAHIP_TUNING=1   # the LUMAHIP_* overrides are honoured only under this gate
 run() {
   env "$@" python bench.py --no-cpu-baseline --no-other-workloads --min-seconds 1.5 2>/dev/null | python -c "
 import json,sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMAHIP_TUNING=1   # the LUMAHIP_* overrides are honoured only under this gate
 run() {
   env "$@" python bench.py --no-cpu-baseline --no-other-workloads --min-seconds 1.0 2>/dev/null | python -c "
 import json,sys

@@ -15,6 +15,7 @@ import lumahdrv_amd as L  # noqa: E402
 
 
 def main():
+    os.environ["LUMAHIP_TUNING"] = "1"   # the LUMAHIP_* overrides are honoured only under this gate
     os.environ["LUMAHIP_ALLOW_ALIASED_FRAMES"] = "1"   # frame stride 0 is refused otherwise (rows of different frames overlap)
     dev = torch.device("cuda:0")
     ctx = L.Context(0)

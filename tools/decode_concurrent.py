@@ -15,13 +15,10 @@ from lumahdrv_amd.placement import CHUNK_BYTES, find_groups, plane_slots  # noqa
 
 
 def make_ctx(grid=None):
-    for k in ("LUMAHIP_GRID_DEC", "LUMAHIP_GRID_ENC"):
-        os.environ.pop(k, None)
-        if grid:
-            os.environ[k] = str(grid)
     c = L.Context(0)
-    for k in ("LUMAHIP_GRID_DEC", "LUMAHIP_GRID_ENC"):
-        os.environ.pop(k, None)
+    if grid:
+        c.tune("grid_enc", grid)
+        c.tune("grid_dec", grid)
     c.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
     return c
 

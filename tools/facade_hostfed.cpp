@@ -1,0 +1,113 @@
+// tools/facade_hostfed.cpp -- what the DROP-IN call costs end to end: LumaEncoder::encode(LumaFrame*) on host frames
+// (include/luma/luma_encoder.h:142-148 of the reference; its callers: lumaenc.cpp:238, test/test_simple_enc.cpp:66), i.e.
+// H2D of 12 B/pixel + the fused kernel + D2H of the planes, one frame per call, synchronous.  PCIe-bound by construction;
+// bench.py prints these figures as `facade_hostfed` next to (never as) the device-resident `value`.
+//   facade_hostfed [w h frames]          -> one JSON line on stdout
+// Rows: a pageable LumaFrame (plain new float[], what the reference's LumaFrame is), the same frame pinned with
+// lumahip_host_register, the batched pinned C-ABI entry point (3-slot pipeline), and LumaDecoder-side decode into a
+// pageable frame (lumahip_decode_frame_host, what LumaDecoder::decode calls).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "luma/luma_encoder.h"
+#include "luma/luma_test_pattern.h"
+#include "lumahip.h"
+
+namespace {
+struct NullSink : LumaPlaneSink {
+    void open(const char *, unsigned int, unsigned int, int, float) {}
+    void addAttachment(unsigned int, const void *, size_t, const char *) {}
+    void writeAttachments() {}
+    bool addFrame(const LumaPlanes &) { return true; }
+    void close() {}
+};
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    const unsigned w = argc > 1 ? std::atoi(argv[1]) : 3840, h = argc > 2 ? std::atoi(argv[2]) : 2160;
+    const int n = argc > 3 ? std::atoi(argv[3]) : 24;
+    try {
+        NullSink sink;
+        LumaEncoder enc;
+        enc.setSink(&sink);
+        FILE *saved = stderr;
+        (void)saved;
+        enc.initialize("null", w, h);
+        // distinct frames (a transcoder never encodes the same memory twice): 4 buffers, cycled
+        std::vector<std::unique_ptr<LumaFrame>> fr;
+        for (int i = 0; i < 4; i++) {
+            fr.emplace_back(new LumaFrame());
+            lumaTestFrame(*fr.back(), w, h);
+            for (size_t j = 0; j < fr.back()->pixelCount(); j += 997)
+                fr.back()->buffer[j] *= 1.0f + 0.01f * i;
+        }
+        const double px = (double)w * h;
+        enc.encode(fr[0].get());  // warm-up: allocations, code object
+        enc.encode(fr[1].get());
+        double t0 = now();
+        for (int i = 0; i < n; i++)
+            enc.encode(fr[i % 4].get());
+        const double pageable = n * px / (now() - t0) / 1e6;
+
+        lumahip_ctx *ctx = enc.getQuantizer()->context();
+        for (auto &f : fr)
+            if (lumahip_host_register(ctx, f->buffer, f->pixelCount() * sizeof(float)) != LUMAHIP_OK)
+                throw LumaException(lumahip_last_error(ctx));
+        enc.encode(fr[0].get());
+        t0 = now();
+        for (int i = 0; i < n; i++)
+            enc.encode(fr[i % 4].get());
+        const double registered = n * px / (now() - t0) / 1e6;
+
+        // batched C-ABI entry point, frames and planes pinned
+        const LumaPlanes &im = enc.getRawFrame();
+        const int st[3] = {im.stride[0], im.stride[1], im.stride[2]};
+        const size_t psz[3] = {(size_t)im.planeHeight(0) * st[0], (size_t)im.planeHeight(1) * st[1], (size_t)im.planeHeight(2) * st[2]};
+        std::vector<std::vector<unsigned char>> pl(3 * 4);
+        std::vector<unsigned char *> plp(3 * (size_t)n);
+        for (int k = 0; k < 4; k++)
+            for (int p = 0; p < 3; p++) {
+                pl[3 * k + p].assign(psz[p] + 4096, 0);
+                (void)lumahip_host_register(ctx, pl[3 * k + p].data(), pl[3 * k + p].size());
+            }
+        std::vector<const float *> rgb(n);
+        for (int i = 0; i < n; i++) {
+            rgb[i] = fr[i % 4]->buffer;
+            for (int p = 0; p < 3; p++)
+                plp[3 * (size_t)i + p] = pl[3 * (i % 4) + p].data();
+        }
+        const LumaEncoderParams prm = enc.getParams();
+        (void)lumahip_encode_frames_host(ctx, rgb.data(), 4, w, h, prm.preScaling, (int)prm.profile, plp.data(), st, nullptr);
+        t0 = now();
+        if (lumahip_encode_frames_host(ctx, rgb.data(), n, w, h, prm.preScaling, (int)prm.profile, plp.data(), st, nullptr) != LUMAHIP_OK)
+            throw LumaException(lumahip_last_error(ctx));
+        const double batch = n * px / (now() - t0) / 1e6;
+
+        // decode into a pageable frame (what LumaDecoder::decode hands back)
+        std::vector<float> out((size_t)3 * w * h);
+        const unsigned char *cpl[3] = {im.planes[0], im.planes[1], im.planes[2]};
+        (void)lumahip_decode_frame_host(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, out.data());
+        t0 = now();
+        for (int i = 0; i < n; i++)
+            if (lumahip_decode_frame_host(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, out.data()) != LUMAHIP_OK)
+                throw LumaException(lumahip_last_error(ctx));
+        const double dec = n * px / (now() - t0) / 1e6;
+        for (auto &f : fr)
+            (void)lumahip_host_unregister(ctx, f->buffer);
+        for (auto &v : pl)
+            (void)lumahip_host_unregister(ctx, v.data());
+        std::printf("{\"width\": %u, \"height\": %u, \"frames\": %d, \"unit\": \"Mpixels/s\", "
+                    "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_encode_registered_frame\": %.1f, "
+                    "\"lumahip_encode_frames_host_pinned\": %.1f, \"decode_frame_host_pageable\": %.1f}\n",
+                    w, h, n, pageable, registered, batch, dec);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

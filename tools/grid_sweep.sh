@@ -1,5 +1,6 @@
 #!/bin/bash
 # persistent-workgroup count sweep of the encode and decode kernels through bench.py (headline workload, placement auto)
+export LUMAHIP_TUNING=1   # the LUMAHIP_* overrides are honoured only under this gate
 run() {
   env "$@" python bench.py --no-cpu-baseline --no-other-workloads --min-seconds 0.8 2>/dev/null | python -c "
 import json,sys

@@ -1,6 +1,9 @@
 // tools/lumaenc.cpp -- the MI355X counterpart of the reference's `lumaenc` application (lumaenc.cpp there) on the C++
 // facade: the same options, defaults, ranges and messages; frames come from an EXR printf pattern or the built-in
-// `__test__` pattern; every frame goes through LumaEncoder::encode (ONE fused HIP kernel).
+// `__test__` pattern; every frame goes through LumaEncoder::encode (ONE fused HIP kernel).  With more than one GPU visible
+// (or LUMAENC_SHARDS=<n> set) the frames are read in groups and go through LumaBatchEncoder instead: the group is split into
+// contiguous blocks, one per GPU, transformed on all GPUs at once and written out in frame order (the reference's loop,
+// lumaenc.cpp:205-243 there, is strictly one frame at a time).
 //
 // Difference, by scope: the reference's encoder hands the Y/U/V planes to libvpx + Matroska and insists on an .mkv
 // output name; this build's downstream is a LumaPlaneSink and, by default, the raw plane stream (.lhs) that carries the
@@ -10,10 +13,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "exr_interface.h"
+#include "luma/luma_batch_encoder.h"
 #include "luma/luma_encoder.h"
+#include "lumahip.h"
 #include "luma_cli.h"
 
 namespace {
@@ -110,17 +117,54 @@ int main(int argc, char *argv[])
             return 0;
         }
         int done = 0;
-        for (unsigned int f = job.first; f <= job.last; f += job.step) {
-            LumaFrame frame;
-            fetch(job, f, frame);
-            if (!encoder.initialized())
-                encoder.initialize(job.output.empty() ? "output.lhs" : job.output.c_str(), frame.width, frame.height, job.verbose);
-            std::fprintf(stderr, "Encoding frame %d... ", f);
-            encoder.encode(&frame);
-            done++;
-            std::fprintf(stderr, "done\n");
+        int gpus = 0;
+        (void)lumahip_device_count(&gpus);
+        const char *shardsEnv = std::getenv("LUMAENC_SHARDS");   // n shards, round-robin over the visible GPUs
+        const int shards = shardsEnv ? std::atoi(shardsEnv) : (gpus > 1 ? gpus : 0);
+        if (shards > 0) {
+            // many GPUs: groups of (frames per shard) x shards frames through LumaBatchEncoder, written in frame order
+            LumaBatchEncoder batch;
+            batch.setParams(params);
+            const char *perEnv = std::getenv("LUMAENC_FRAMES_PER_SHARD");
+            const size_t group = (size_t)shards * (size_t)(perEnv && std::atoi(perEnv) > 0 ? std::atoi(perEnv) : 4);
+            std::vector<std::unique_ptr<LumaFrame>> held;
+            auto flush = [&]() {
+                if (held.empty())
+                    return;
+                std::vector<LumaFrame *> ptrs;
+                for (auto &fr : held)
+                    ptrs.push_back(fr.get());
+                std::fprintf(stderr, "Encoding %zu frames on %u shard(s)... ", held.size(), batch.shards());
+                batch.encode(ptrs.data(), (unsigned int)ptrs.size());
+                done += (int)held.size();
+                held.clear();
+                std::fprintf(stderr, "done\n");
+            };
+            for (unsigned int f = job.first; f <= job.last; f += job.step) {
+                std::unique_ptr<LumaFrame> frame(new LumaFrame());
+                fetch(job, f, *frame);
+                if (!batch.initialized())
+                    batch.initialize(job.output.empty() ? "output.lhs" : job.output.c_str(), frame->width, frame->height, job.verbose,
+                                     NULL, shards);
+                held.push_back(std::move(frame));
+                if (held.size() == group)
+                    flush();
+            }
+            flush();
+            batch.finish();
+        } else {
+            for (unsigned int f = job.first; f <= job.last; f += job.step) {
+                LumaFrame frame;
+                fetch(job, f, frame);
+                if (!encoder.initialized())
+                    encoder.initialize(job.output.empty() ? "output.lhs" : job.output.c_str(), frame.width, frame.height, job.verbose);
+                std::fprintf(stderr, "Encoding frame %d... ", f);
+                encoder.encode(&frame);
+                done++;
+                std::fprintf(stderr, "done\n");
+            }
+            encoder.finish();
         }
-        encoder.finish();
         std::fprintf(stderr, "\n\nEncoding finished. %d frames encoded.\n", done);
     } catch (const lumacli::UsageError &e) {
         std::fprintf(stderr, "\nlumaenc input error: %s\n", e.what());

@@ -23,12 +23,11 @@ def main():
     cases += [(L.PTF_LOG, 12, L.CS_LUV, 8, None), (L.PTF_PSI, 11, L.CS_LUV, 8, None), (L.PTF_PQ, 11, L.CS_LUV, 8, "literal"),
               (L.PTF_PQ, 13, L.CS_LUV, 8, None)]
     for ptf, bits, cs, bitsC, force in cases:
-        if force:
-            os.environ["LUMAHIP_FORCE_LITERAL"] = "1"
         ctx = L.Context(0)
+        if force:
+            ctx.tune("force_literal", 1)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(ptf, bits, cs, bitsC, 1e4, 0.005, L.build_lut(ptf, bits))
-        os.environ.pop("LUMAHIP_FORCE_LITERAL", None)
         info = ctx.quantizer_info()
         ctx.synth_frames_device(src.data_ptr(), n3, B, w, h)
         for profile in (2, 3, 0, 1):

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["LUMAHIP_LIB"] = os.path.join(ROOT, "lumahdrv_amd", "lib_exp", "liblumahip.so")
+os.environ["LUMAHIP_TUNING"] = "1"   # the LUMAHIP_* overrides are honoured only under this gate
 os.environ["LUMAHIP_ALLOW_ALIASED_FRAMES"] = "1"      # frame stride = one plane: the layout check would refuse it
 import torch  # noqa: E402
 

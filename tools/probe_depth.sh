@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMAHIP_TUNING=1   # the LUMAHIP_* overrides are honoured only under this gate
 for r in 1 2; do
 for e in "X=1" "LUMAHIP_PROBE_DEPTH=2" "LUMAHIP_PROBE_DEPTH=4" "LUMAHIP_PROBE_DEPTH=2 LUMAHIP_GRID_ENC=512" "LUMAHIP_PROBE_DEPTH=4 LUMAHIP_GRID_ENC=512" "LUMAHIP_PROBE_DEPTH=3 LUMAHIP_GRID_ENC=768"; do
   env $e python bench.py --no-cpu-baseline --no-other-workloads --min-seconds 0.5 2>/dev/null | python -c "

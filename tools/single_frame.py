@@ -13,6 +13,7 @@ import lumahdrv_amd as L  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     for blk, pcu in ((256, 0), (256, 2), (256, 4), (512, 0), (512, 2), (1024, 1), (1024, 2)):
+        os.environ["LUMAHIP_TUNING"] = "1"   # the LUMAHIP_* overrides are honoured only under this gate
         os.environ["LUMAHIP_BLOCK"] = str(blk)
         os.environ["LUMAHIP_BLOCKS_PER_CU"] = str(pcu)
         ctx = L.Context(0)

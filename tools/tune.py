@@ -27,6 +27,7 @@ def main():
     for bt, pc in itertools.product(blocks, percu):
         if pc * bt > 2048:
             continue
+        os.environ["LUMAHIP_TUNING"] = "1"   # the LUMAHIP_* overrides are honoured only under this gate
         os.environ["LUMAHIP_BLOCK"] = str(bt)
         os.environ["LUMAHIP_BLOCKS_PER_CU"] = str(pc)
         ctx = L.Context(0)
