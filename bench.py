@@ -20,10 +20,18 @@ parameters from rank 0 before the timed region.  `--stream-frames F` switches to
 F-frame stream (default use: 2000) block-sharded over the ranks (250 per GPU at N = 8, strong scaling), per-frame
 plane digests all_gathered in stream order and spot-checked by rank 0.
 
-Extra fields in the same line (not part of `value`): decode and encode+decode round trip, the roofline of the encode
-kernel (HIP events on the launch stream, live), `other_workloads` (BASELINE configs[2] HDR10/YCbCr at 4K and configs[3]
-LOG-12 at 7680x4320, each with its own roofline block and its decode rate; N = 1 only) and the CPU reference timed on this host
-(`cpu_baseline`, N = 1 only).
+The K launches of a region are independent batches, so they run inside ONE unordered section of the C ABI
+(lumahip_begin_unordered ... lumahip_end_unordered, `--lanes`, default 2: successive batches alternate between two
+internal streams, so one batch's ramp-up and tail overlap its neighbours' steady state).  The hipEvent pair brackets the
+whole section on the context's stream; `kernel_ms` = that window / K.  `--lanes 0` (and the `*_ordered` fields of the default
+run) is the same K launches back to back on one stream.
+
+Extra fields in the same line (not part of `value`): decode (its own `decode_roofline` block with a decode-shaped
+traffic-only probe) and encode+decode round trip, the roofline of the encode kernel (HIP events on the launch stream, live),
+`value_placement_off` (the same kernels on plainly allocated buffers), `other_workloads` (BASELINE configs[2] HDR10/YCbCr at
+4K and configs[3] LOG-12 at 7680x4320, each with its own roofline block and its decode rate; N = 1 only), `facade_hostfed`
+(LumaEncoder::encode(LumaFrame*) end to end on host frames -- PCIe-bound, never `value`) and the CPU reference timed on this
+host (`cpu_baseline`, N = 1 only).
 """
 import argparse
 import json
@@ -63,6 +71,16 @@ def parse():
     ap.add_argument("--max-repeats", type=int, default=400)
     ap.add_argument("--stream-frames", type=int, default=0,
                     help="BASELINE configs[4] mode: ONE stream of this many frames (2000) block-sharded over the ranks")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="streams of the unordered section the K launches of a region run in (0 = one stream, launches back to back)")
+    ap.add_argument("--driver", default="torch", choices=["torch", "multi"],
+                    help="--stream-frames mode: 'torch' = one process per GPU under torch.distributed (RCCL); 'multi' = ONE process "
+                         "driving every visible GPU through the C ABI's lumahip_multi_* layer (table broadcast with RCCL from C++)")
+    ap.add_argument("--dump-digests", default="", help="--stream-frames mode: write the per-frame digests (stream order) to this JSON file")
+    ap.add_argument("--decode-layout", default="auto", choices=["auto", "packed"],
+                    help="auto: with --placement auto the decoded frames are written with their R, G, B planes in three HBM region "
+                         "groups (lumahip_decode_frames_device_planar); packed: the LumaFrame layout always")
+    ap.add_argument("--no-facade-hostfed", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
@@ -95,6 +113,12 @@ def free_port():
     return p
 
 
+def respawn_command(gpus, argv, port):
+    """the launcher line `python bench.py --gpus N` turns itself into: one rank per GPU of ONE node, rendezvous on 127.0.0.1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def respawn(args):
     """`python bench.py --gpus N` with no launcher environment: run the same command line under torch.distributed.run,
     one rank per GPU, and pass its single JSON line through."""
@@ -102,8 +126,7 @@ def respawn(args):
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices"
                          % (args.gpus, have, args.gpus))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = respawn_command(args.gpus, sys.argv[1:], free_port())
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.call(cmd, env=env))
@@ -112,37 +135,55 @@ def respawn(args):
 class Timer:
     """W warm-up steps, then EXACTLY K steps between barrier + synchronize, wall-clock MAX over ranks; that K-step region
     is repeated (warm-up only before the first) until min_seconds of device time is accumulated.  The kernels run on
-    torch's current stream (ctx.set_stream), so the torch.cuda.Event pair around the K launches is a hipEvent pair on the
-    launch stream: `dev_ms` = device time of each region."""
+    torch's current stream (ctx.set_stream) or, with `lanes`, in an unordered section that forks from and joins into it, so
+    the torch.cuda.Event pair around the K launches is a hipEvent pair on the launch stream bracketing all of them:
+    `dev_ms` = device time of each region.  The wall clock is read after the device has drained and BEFORE the trailing
+    barrier (a RCCL barrier is a kernel launch plus a host sync that only N > 1 would pay); the MAX over ranks is taken from
+    the per-rank times afterwards."""
 
-    def __init__(self, K, Wm, use_dist, dev, min_seconds, max_repeats):
+    def __init__(self, K, Wm, use_dist, dev, min_seconds, max_repeats, ctx=None, lanes=0):
         self.K, self.Wm, self.use_dist, self.dev = K, Wm, use_dist, dev
         self.min_seconds, self.max_repeats = min_seconds, max_repeats
+        self.ctx, self.lanes = ctx, lanes
+        self.cuda = torch.device(dev).type == "cuda"      # (the gloo tests drive the same loop on the CPU: wall clock only)
 
-    def region(self, fn, first):
-        torch.cuda.synchronize()
+    def _sync(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+
+    def region(self, fn, first, lanes):
+        self._sync()
         if self.use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._sync()
+        e0 = e1 = None
+        if self.cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        e0.record()
+        if self.cuda:
+            e0.record()
+        if lanes:
+            self.ctx.begin_unordered(lanes)
         for i in range(self.K):
             fn(first + i)
-        e1.record()
-        torch.cuda.synchronize()
+        if lanes:
+            self.ctx.end_unordered()
+        if self.cuda:
+            e1.record()
+        self._sync()
+        wall = time.perf_counter() - t0
         if self.use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, e0.elapsed_time(e1)
+        return wall, (e0.elapsed_time(e1) if self.cuda else 1e3 * wall)
 
-    def run(self, fn):
+    def run(self, fn, lanes=None):
+        lanes = self.lanes if lanes is None else lanes
         for i in range(self.Wm):
             fn(i)
         walls, devs = [], []
         step = self.Wm
         while True:
-            wall, dev_ms = self.region(fn, step)
+            wall, dev_ms = self.region(fn, step, lanes)
             step += self.K
             walls.append(wall)
             devs.append(dev_ms)
@@ -153,12 +194,18 @@ class Timer:
                 dist.broadcast(more, src=0)
             if int(more.item()) == 0:
                 break
+        mine = float(np.median(walls))                           # this rank's median region
         t = torch.tensor(walls, dtype=torch.float64, device=self.dev)
+        ranks = [mine]
         if self.use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per region: the slowest rank
+            g = [torch.zeros(1, dtype=torch.float64, device=self.dev) for _ in range(dist.get_world_size())]
+            dist.all_gather(g, torch.tensor([mine], dtype=torch.float64, device=self.dev))
+            ranks = [float(x.item()) for x in g]
         walls = t.cpu().numpy()
         return {"wall_median": float(np.median(walls)), "wall_min": float(walls.min()), "wall_max": float(walls.max()),
-                "dev_ms_median": float(np.median(devs)), "repeats": len(devs), "seconds": float(walls.sum())}
+                "dev_ms_median": float(np.median(devs)), "repeats": len(devs), "seconds": float(walls.sum()),
+                "rank_wall_medians": ranks}
 
 
 def load_profile(path, workload, px_step, sha):
@@ -174,8 +221,9 @@ def load_profile(path, workload, px_step, sha):
     return None
 
 
-def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha, pool=None):
-    """one workload: resident synthetic stream, encode timed (plus decode / round trip for the main one), roofline block"""
+def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha, pool=None, legs="full"):
+    """one workload: resident synthetic stream, encode timed (plus decode / round trip for the main one), roofline blocks.
+    legs: "full" = every leg; "encode" = the encode leg only (the placement-off comparison)."""
     from lumahdrv_amd.sharding import broadcast_quantizer
     ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
     cfg0 = lut0 = None
@@ -188,27 +236,34 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_quantizer(ptf, bits, cs, bitsC, maxLum, minLum, lut)
 
-    n3 = 3 * w * h
+    n1 = w * h
+    n3 = 3 * n1
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
     per_frame = n3 * 4 * 2 + sum(psz)                      # input + decoded output + planes
     free, _total = torch.cuda.mem_get_info(dev)
     want_frames = 500 if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)    # >= 4 GB of distinct input: >> 256 MB MALL
+    striped = False
     if pool is not None:
         from lumahdrv_amd.placement import CHUNK_BYTES, slots
         ypc, yslot = slots(CHUNK_BYTES, B * psz[0])
         uvpc, uvslot = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        spc, sslot = slots(CHUNK_BYTES, B * n1 * 4)       # one colour plane of one batch per slot
         if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
             pool = None
     if pool is not None:
-        # float frames: one chunk per batch of input, one per batch of decoded output; Y planes of `ypc` batches per chunk
-        # of one group; U and V planes of `uvpc` batches per chunk of another (lumahdrv_amd/placement.py)
+        # float frames: one chunk per batch of input; decoded output either packed (one chunk per batch) or, when the pool
+        # kept chunks of three region groups for it, with the R, G and B planes of a batch in three different groups
+        # (lumahip_decode_frames_device_planar); Y planes of `ypc` batches per chunk of one group; U and V planes of `uvpc`
+        # batches per chunk of another (lumahdrv_amd/csrc/lumahip_pool.hip)
+        striped = legs == "full" and args.decode_layout == "auto" and spc >= 1 and min(len(g) for g in pool.striped) >= 1
         nbatch = max(1, want_frames // B)
-        while nbatch > 1 and (nbatch * 2 > len(pool.float) or -(-nbatch // uvpc) > len(pool.uv)
-                              or -(-nbatch // ypc) > len(pool.y)):
+        while nbatch > 1 and (nbatch * (1 if striped else 2) > len(pool.float) or -(-nbatch // uvpc) > len(pool.uv)
+                              or -(-nbatch // ypc) > len(pool.y) or (striped and -(-nbatch // spc) > min(len(g) for g in pool.striped))):
             nbatch -= 1
         src_c = pool.take_float(nbatch)                    # fastest first: the input gets the best chunks
-        out_c = pool.take_float(nbatch)
+        out_c = [] if striped else pool.take_float(nbatch)
+        rgb_c = pool.take_striped(-(-nbatch // spc)) if striped else None
         uv_c = pool.take_uv(-(-nbatch // uvpc))
         y_c = pool.take_y(-(-nbatch // ypc))
         for c in uv_c + y_c:
@@ -217,16 +272,22 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
 
         def ptrs(b):
             u = uv_c[b // uvpc].data_ptr() + (b % uvpc) * uvslot
-            return (src_c[b].data_ptr(), out_c[b].data_ptr(), [y_c[b // ypc].data_ptr() + (b % ypc) * yslot, u, u + vo])
+            if striped:
+                o = [rgb_c[k][b // spc].data_ptr() + (b % spc) * sslot for k in range(3)]
+            else:
+                o = [out_c[b].data_ptr() + k * n1 * 4 for k in range(3)]
+            return (src_c[b].data_ptr(), o, [y_c[b // ypc].data_ptr() + (b % ypc) * yslot, u, u + vo])
     else:
         nbatch = max(1, min(want_frames // B, int(free * 0.8 // per_frame) // B))
         src = torch.empty(nbatch * B * n3, dtype=torch.float32, device=dev)
-        out = torch.empty(nbatch * B * n3, dtype=torch.float32, device=dev)
+        out = torch.empty(nbatch * B * n3 if legs == "full" else 4, dtype=torch.float32, device=dev)
         planes = [torch.zeros(nbatch * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
 
         def ptrs(b):
-            return (src.data_ptr() + b * B * n3 * 4, out.data_ptr() + b * B * n3 * 4,
+            o = out.data_ptr() + b * B * n3 * 4
+            return (src.data_ptr() + b * B * n3 * 4, [o + k * n1 * 4 for k in range(3)],
                     [planes[p].data_ptr() + b * B * psz[p] for p in range(3)])
+    out_fs = n1 if striped else n3                         # frame stride of the decoded output (floats)
     nfr = nbatch * B
     first = rank * nfr                                     # each rank has its own stream (weak scaling)
     for b in range(nbatch):
@@ -239,58 +300,105 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
 
     def dec(i):
         _, o, pl = ptrs(i % nbatch)
-        ctx.decode_frames_device(pl, st, psz, B, w, h, profile, sc, o, n3)
+        ctx.decode_frames_device_planar(pl, st, psz, B, w, h, profile, sc, o, out_fs)
 
-    tm = Timer(K, Wm, use_dist, dev, args.min_seconds, args.max_repeats)
+    lanes = max(0, args.lanes)
+    tm = Timer(K, Wm, use_dist, dev, args.min_seconds, args.max_repeats, ctx, lanes)
     px_step = float(B) * w * h
     te = tm.run(enc)
 
     def rate(t):
         return world * K * px_step / t / 1e6
 
+    def per_rank(t):
+        v = sorted(1e3 * x / K for x in t["rank_wall_medians"])
+        return {"min": round(v[0], 4), "median": round(float(np.median(v)), 4), "max": round(v[-1], 4)}
+
     r = {"value": round(rate(te["wall_median"]), 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * te["wall_median"] / K, 4),
          "ms_per_step_min": round(1e3 * te["wall_min"] / K, 4), "ms_per_step_max": round(1e3 * te["wall_max"] / K, 4),
-         "repeats": te["repeats"], "timed_seconds": round(te["seconds"], 3),
+         "ms_per_step_over_ranks": per_rank(te),
+         "repeats": te["repeats"], "timed_seconds": round(te["seconds"], 3), "lanes": lanes,
          "workload": "%dx%d %s encode (%s, LUT quantize, 4:2:0 16-bit pack), %d frames/step, %d-frame resident stream per GPU"
                      % (w, h, desc, xf_desc, B, nfr),
          "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
          "distinct_input_GB_per_gpu": round(nfr * n3 * 4 / 1e9, 2)}
+    if legs == "encode":
+        ctx.close()
+        if pool is not None:
+            pool.give_back(src_c + out_c, y_c, uv_c, rgb_c)
+        else:
+            del src, out, planes
+            torch.cuda.empty_cache()
+        return r, cfg
     td = tm.run(dec)                                       # (the planes every batch holds are the encode leg's)
     r["decode_mpix_s"] = round(rate(td["wall_median"]), 1)
+    r["decode_output_layout"] = ("R, G, B planes of a batch in three HBM region groups (lumahip_decode_frames_device_planar)"
+                                 if striped else "packed LumaFrame layout")
+    teo = tdo = None
+    if lanes:
+        teo = tm.run(enc, lanes=0)                         # the same launches back to back on one stream
+        tdo = tm.run(dec, lanes=0)
+        r["value_ordered"] = round(rate(teo["wall_median"]), 1)
+        r["decode_mpix_s_ordered"] = round(rate(tdo["wall_median"]), 1)
     if main:
-        trt = tm.run(lambda i: (enc(i), dec(i)))
+        # encode batch i, decode batch i: dependent, so ordered on one stream
+        trt = tm.run(lambda i: (enc(i), dec(i)), lanes=0)
         r["roundtrip_mpix_s"] = round(rate(trt["wall_median"]), 1)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: hipEvents over the timed regions (median region / K), rank 0
+        nprobe = max(5, min(25, nbatch))
         avg_ms = te["dev_ms_median"] / K
         iso = [ctx.time_launches(0, 1, ptrs(i % nbatch)[0], n3, B, w, h, sc, profile, ptrs(i % nbatch)[2], st, psz)
-               for i in range(max(5, min(25, nbatch)))]
-        achieved = BYTES_PER_PIXEL * px_step / (avg_ms * 1e-3) / 1e9
-        hbm = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-               "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step}
-        probe_ms = None
+               for i in range(nprobe)]
+        probe_ms = dprobe_ms = None
         if profile == 2 and w % 4 == 0:
-            # the same loads and stores with no arithmetic: what the memory system gives this traffic mix on THIS box.
-            # (overwrites the planes of these batches with garbage; nothing reads them afterwards)
+            # the same loads and stores with no arithmetic: what the memory system gives each traffic mix on THIS box.
+            # (the decode probe overwrites the decoded frames, the encode probe the planes; nothing reads them afterwards)
+            dprobe_ms = float(np.median([ctx.probe_decode_traffic(ptrs(i % nbatch)[2], st, psz, B, w, h, ptrs(i % nbatch)[1], out_fs)
+                                         for i in range(nprobe)]))
             probe_ms = float(np.median([ctx.probe_encode_traffic(ptrs(i % nbatch)[0], n3, B, w, h, ptrs(i % nbatch)[2], st, psz)
-                                        for i in range(max(5, min(25, nbatch)))]))
+                                        for i in range(nprobe)]))
         tr = load_profile(os.path.join(args.profile_dir, "traffic_latest.json"), name, px_step, sha)
         if tr and tr.get("pixels_per_launch") != px_step:
             tr = None                                     # captured for a different launch size: not this launch's bytes
-        common = {"kernel": kname, "kernel_ms": round(avg_ms, 4), "kernel_ms_isolated_launch": round(float(np.median(iso)), 4),
-                  "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                  "traffic_source": ("rocprofv3 PMC passes of tools/profile_round.sh (2 x FETCH_SIZE + WRITE_SIZE), captured "
-                                     "from these kernel sources at commit %s: %s" % (tr.get("commit", "?"), tr.get("tag", "?")))
-                                    if tr else "no PMC capture of the current kernel sources in profiles/ (null, not a stale figure)",
-                  "traffic_only_ms": None if probe_ms is None else round(probe_ms, 4),
-                  "frac_of_traffic_only_rate": None if probe_ms is None else round(probe_ms / avg_ms, 3)}
+
+        def hbm_block(ms, ms_ordered, ms_iso, probe, traffic_key, kern):
+            achieved = BYTES_PER_PIXEL * px_step / (ms * 1e-3) / 1e9
+            blk = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
+                   "kernel": kern, "kernel_ms": round(ms, 4),
+                   "kernel_ms_is": ("hipEvent window over the K launches of a region / K; the launches overlap on %d streams "
+                                    "(lumahip_begin_unordered)" % lanes) if lanes else "hipEvent window over K back-to-back launches / K",
+                   "kernel_ms_ordered": None if ms_ordered is None else round(ms_ordered, 4),
+                   "frac_ordered": None if ms_ordered is None else round(BYTES_PER_PIXEL * px_step / (ms_ordered * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "kernel_ms_isolated_launch": None if ms_iso is None else round(ms_iso, 4),
+                   "traffic": tr.get(traffic_key) if tr else None,
+                   "traffic_source": ("rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE calibrated on the "
+                                      "traffic-only probe of the same access pattern), captured from these kernel sources at commit "
+                                      "%s: %s" % (tr.get("commit", "?"), tr.get("tag", "?")))
+                                     if tr else "no PMC capture of the current kernel sources in profiles/ (null, not a stale figure)",
+                   "traffic_only_ms": None if probe is None else round(probe, 4),
+                   "frac_of_traffic_only_rate": None if probe is None else round(probe / (ms_ordered if ms_ordered else ms), 3)}
+            return blk
+
+        enc_blk = hbm_block(avg_ms, teo["dev_ms_median"] / K if teo else None, float(np.median(iso)), probe_ms,
+                            "hbm_bytes_per_launch", kname)
+        dkname = kname.replace("k_encode", "k_decode").replace("LDS threshold records", "table in LDS")
+        diso = [ctx.time_launches(1, 1, ptrs(i % nbatch)[1][0], n3, B, w, h, sc, profile, ptrs(i % nbatch)[2], st, psz)
+                for i in range(nprobe)] if not striped else None
+        dec_blk = hbm_block(td["dev_ms_median"] / K, tdo["dev_ms_median"] / K if tdo else None,
+                            float(np.median(diso)) if diso else None, dprobe_ms, "decode_hbm_bytes_per_launch", dkname)
+        dec_blk["output_layout"] = r["decode_output_layout"]
         mix = load_profile(os.path.join(args.profile_dir, "valu_mix_latest.json"), name, px_step, sha)
         if cs == 2:
             # YCbCr: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
             # issue cost measured by tools/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
             # conversions / compares / selects / min / max 4, transcendental 8); peak = every SIMD issuing every cycle.
             peak = N_SIMD * CLOCK_GHZ                                  # G SIMD-cycles / s
+            common = {k: enc_blk[k] for k in ("kernel", "kernel_ms", "kernel_ms_is", "kernel_ms_ordered", "kernel_ms_isolated_launch",
+                                              "traffic", "traffic_source", "traffic_only_ms", "frac_of_traffic_only_rate")}
+            hbm = {k: enc_blk[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
             if mix:
                 cyc = mix["issue_cycles_per_launch"] * (px_step / mix["pixels_per_launch"])   # SIMD-cycles of VALU issue
                 ach = cyc / (avg_ms * 1e-3) / 1e9                      # G SIMD-cycles / s actually spent issuing VALU
@@ -302,12 +410,14 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 r["roofline"] = dict({"bound": "valu", "achieved": None, "peak": round(peak, 1), "unit": "G SIMD-issue-cycles/s",
                                       "frac": None, "note": "no instruction-mix capture of the current kernel sources in profiles/",
                                       "hbm": hbm}, **common)
+            r["decode_roofline"] = {"bound": "valu", "hbm": dec_blk}
         else:
-            r["roofline"] = dict(dict({"bound": "hbm"}, **hbm), **common)
-            r["roofline"]["decode_achieved_GBs"] = round(BYTES_PER_PIXEL * px_step / (td["dev_ms_median"] / K * 1e-3) / 1e9, 1)
+            r["roofline"] = enc_blk
+            r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]
+            r["decode_roofline"] = dec_blk
     ctx.close()
     if pool is not None:
-        pool.give_back(src_c + out_c, y_c, uv_c)
+        pool.give_back(src_c + out_c, y_c, uv_c, rgb_c)
     else:
         del src, out, planes
         torch.cuda.empty_cache()
@@ -394,7 +504,7 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     if use_dist:
         dist.all_reduce(ksteps, op=dist.ReduceOp.MAX)
     K = int(ksteps.item())                      # every rank issues K step calls (empty ones past its shard)
-    tm = Timer(K, 0, use_dist, dev, args.min_seconds, args.max_repeats)
+    tm = Timer(K, 0, use_dist, dev, args.min_seconds, args.max_repeats, ctx, max(0, args.lanes))
     enc(0)                                      # warm-up: one step
     te = tm.run(enc)
     torch.cuda.synchronize()
@@ -405,6 +515,8 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
         nb = min(B, nfr - k * B)
         dig += frame_digests(plane_views(k, nb), psz, nb, dev).cpu().tolist()
     allv = gather_in_stream_order(dig, F, dev)
+    if args.dump_digests and rank == 0:
+        json.dump(allv, open(args.dump_digests, "w"))
     checked = 0
     if rank == 0:
         one = torch.empty(n3, dtype=torch.float32, device=dev)
@@ -437,6 +549,80 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     ctx.close()
     if pool is not None:
         pool.close()
+    return res
+
+
+def run_stream_multi(L, args):
+    """BASELINE configs[4] through the C ABI's many-GPU layer (lumahip_multi_*): ONE process, one shard (context + stream)
+    per GPU, the table built once on the host and broadcast to the GPUs with RCCL from C++, the F-frame stream block-sharded
+    with lumahip_shard_range, every shard resident in its GPU's HBM.  A timed region = every shard encodes its block once;
+    the host enqueues step k on every GPU before step k+1 (launches are asynchronous), then waits for all of them."""
+    from lumahdrv_amd import capi
+    name = args.workload
+    ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
+    w, h, B, F = args.width, args.height, args.frames_per_step, args.stream_frames
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    ns = args.gpus
+    m = capi.Multi(list(range(ns)))
+    m.set_quantizer(ptf, bits, cs, bitsC, maxLum, minLum, L.build_lut(ptf, bits, maxLum, minLum))
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    shards = [capi.shard_range(F, s, ns) for s in range(ns)]
+    src, planes = [], []
+    for s in range(ns):
+        dev = torch.device("cuda", s)
+        nfr = len(shards[s])
+        free, _t = torch.cuda.mem_get_info(dev)
+        if (n3 * 4 + sum(psz)) * max(nfr, 1) > free * 0.9:
+            raise SystemExit("shard %d: %d frames do not fit in HBM" % (s, nfr))
+        src.append(torch.empty(max(nfr, 1) * n3, dtype=torch.float32, device=dev))
+        planes.append([torch.zeros(max(nfr, 1) * psz[p], dtype=torch.uint8, device=dev) for p in range(3)])
+        c = m.ctx(s)
+        for k in range(0, nfr, B):
+            c.synth_frames_device(src[s].data_ptr() + k * n3 * 4, n3, min(B, nfr - k), w, h, SEED, shards[s].start + k)
+    m.sync()
+    steps = max((len(r) + B - 1) // B for r in shards)
+
+    def one_pass():
+        for k in range(steps):
+            counts = [max(0, min(B, len(shards[s]) - k * B)) for s in range(ns)]
+            m.encode_frames_device([src[s].data_ptr() + k * B * n3 * 4 for s in range(ns)], n3, counts, w, h, sc, profile,
+                                   [[planes[s][p].data_ptr() + k * B * psz[p] for p in range(3)] for s in range(ns)], st, psz)
+        m.sync()
+
+    one_pass()                                  # warm-up
+    walls = []
+    while sum(walls) < args.min_seconds and len(walls) < args.max_repeats:
+        t0 = time.perf_counter()
+        one_pass()
+        walls.append(time.perf_counter() - t0)
+    dig = []
+    for s in range(ns):
+        nfr = len(shards[s])
+        if nfr:
+            dig += [int(x) & 0x7FFFFFFFFFFFFFFF for x in frame_digests(planes[s], psz, nfr, torch.device("cuda", s)).cpu().tolist()]
+    if args.dump_digests:
+        json.dump(dig, open(args.dump_digests, "w"))
+    wall = float(np.median(walls))
+    px = float(F) * w * h
+    res = {"metric": "Mpixels/s HDR quantize (4K PQ Lu'v' 11-bit), %d-frame stream block-sharded over the GPUs" % F,
+           "value": round(px / wall / 1e6, 1), "unit": "Mpixels/s", "n_gpus": ns, "steps": steps, "warmup": 1,
+           "ms_per_step": round(1e3 * wall / max(steps, 1), 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%dx%d %s encode, ONE %d-frame stream sharded in contiguous blocks (%d frames on shard 0), "
+                                  "%d frames/step" % (w, h, desc, F, len(shards[0]), B),
+                      "frames_per_step": B, "width": w, "height": h, "parallelism": "frame-sharded x%d" % ns,
+                      "driver": "one process, lumahip_multi_* (C ABI): one context + stream per GPU, table broadcast with RCCL: %s"
+                                % m.used_rccl()},
+           "repeats": len(walls), "timed_seconds": round(sum(walls), 3),
+           "ms_per_region_min_median_max": [round(1e3 * min(walls), 3), round(1e3 * wall, 3), round(1e3 * max(walls), 3)],
+           "digests": {"gathered_in_stream_order": len(dig),
+                       "stream_digest": "%016x" % (sum((i + 1) * v for i, v in enumerate(dig)) & 0xFFFFFFFFFFFFFFFF)},
+           "placement": {"mode": "off (plain allocations)"}}
+    m.close()
     return res
 
 
@@ -480,35 +666,58 @@ def cpu_baseline(args, cfg, w, h):
 
 
 def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True):
-    """--placement auto: the chunk pool the resident streams are carved from (None: plain allocations)"""
+    """--placement auto: the chunk pool (C ABI lumahip_pool_*) the resident streams are carved from (None: plain allocations)"""
     if args.placement != "auto":
         return None
     try:
         from lumahdrv_amd.placement import CHUNK_BYTES, HbmChunkPool, slots
-        n3 = 3 * w * h
+        n1 = w * h
+        n3 = 3 * n1
         _, hs, st, _ = L.plane_geometry(w, h, 2)
         psz = [hs[p] * st[p] for p in range(3)]
         ypc, _ = slots(CHUNK_BYTES, B * psz[0])
         uvpc, _ = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        spc, _ = slots(CHUNK_BYTES, B * n1 * 4)
         if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
             return None
         nb = nbatches if nbatches else 500 // B            # default: the 500-frame stream, input + decoded output
-        n_float, n_y, n_uv = (2 if with_output else 1) * nb, -(-nb // ypc), -(-nb // uvpc)
+        stripe = with_output and args.decode_layout == "auto" and spc >= 1
+        n_float = nb * (2 if (with_output and not stripe) else 1)
+        n_y, n_uv, n_striped = -(-nb // ypc), -(-nb // uvpc), (-(-nb // spc) if stripe else 0)
         ctx = L.Context(local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
-        pool = HbmChunkPool(ctx, dev, n_float, n_y, n_uv)
+        pool = HbmChunkPool(ctx, dev, n_float, n_y, n_uv, n_striped)
         ctx.close()
-        return pool if pool.float and pool.y and pool.uv else None
+        if pool.float and pool.y and pool.uv:
+            return pool
+        pool.close()
+        return None
     except Exception as e:      # placement is an optimisation, never a reason to fail the bench
         sys.stderr.write("bench.py: chunk pool unavailable (%r), plain allocations\n" % (e,))
         torch.cuda.empty_cache()
         return None
 
 
+def facade_hostfed(w, h):
+    """LumaEncoder::encode(LumaFrame*) end to end on HOST frames (tools/facade_hostfed.cpp, the C++ facade): H2D + kernel +
+    D2H per call -- the reference's drop-in call as its own callers make it.  PCIe-bound; reported beside, never as, `value`."""
+    exe = os.path.join(ROOT, "lumahdrv_amd", "bin", "facade_hostfed")
+    try:
+        out = subprocess.run([exe, str(w), str(h), "24"], capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        d["what"] = ("host frames through the C++ facade, one frame per call, synchronous (H2D 12 B/px + fused kernel + D2H 3 B/px); "
+                     "pageable = plain new float[] as the reference's LumaFrame, staged by the context's copy threads")
+        return d
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    multi_driver = args.stream_frames > 0 and args.driver == "multi"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not multi_driver:
         respawn(args)
     # The contract is ONE JSON line on stdout.  Libraries (RCCL with NCCL_DEBUG=VERSION, the ROCm runtime) print
     # banners to the C-level stdout, flushed at exit -- i.e. after anything Python prints.  So file descriptor 1 is
@@ -516,6 +725,14 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if multi_driver:
+        # ONE process drives every GPU through the C ABI's many-GPU layer: no torch.distributed, no ranks
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        import lumahdrv_amd as L
+        res = run_stream_multi(L, args)
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -563,12 +780,22 @@ def main():
                        "distinct_input_GB_per_gpu": r["distinct_input_GB_per_gpu"]},
             "repeats": r["repeats"], "timed_seconds": r["timed_seconds"],
             "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
-            "decode_mpix_s": r["decode_mpix_s"], "roundtrip_mpix_s": r["roundtrip_mpix_s"],
+            "ms_per_step_over_ranks": r["ms_per_step_over_ranks"], "lanes": r["lanes"],
+            "value_ordered": r.get("value_ordered"), "decode_mpix_s_ordered": r.get("decode_mpix_s_ordered"),
+            "decode_mpix_s": r["decode_mpix_s"], "decode_output_layout": r["decode_output_layout"],
+            "roundtrip_mpix_s": r["roundtrip_mpix_s"],
             "kernel_source_sha": sha,
             "placement": dict({"mode": args.placement}, **(pool.stats if pool is not None else {})),
         }
         if rank == 0:
             res["roofline"] = r["roofline"]
+            res["decode_roofline"] = r["decode_roofline"]
+        if pool is not None and args.workload == "pq11_luv":
+            # the same kernels on plainly allocated buffers (a 200-frame resident stream, 20 GB >> the 256 MB MALL):
+            # what a caller that does not place its buffers gets
+            ro, _ = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha, None,
+                                 legs="encode")
+            res["value_placement_off"] = ro["value"]
         # ---- the other single-GPU configurations of BASELINE.json, same run, each with its own roofline (N = 1 only)
         if n_gpus == 1 and not args.no_other_workloads and args.workload == "pq11_luv" and (w, h) == (W4K, H4K):
             others = {}
@@ -579,6 +806,8 @@ def main():
             res["other_workloads"] = others
         if pool is not None:
             pool.close()
+        if rank == 0 and n_gpus == 1 and not args.no_facade_hostfed:
+            res["facade_hostfed"] = facade_hostfed(w, h)
         if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cfg, w, h)
 

@@ -191,8 +191,8 @@ int lumahip_decode_frames_device_planar(lumahip_ctx *ctx, const unsigned char *c
  * read-only state, src/luma_quantizer.cpp:215-264,267-482 keep nothing between frames), so a caller with several batches to
  * process need not order them against each other.  Between lumahip_begin_unordered and lumahip_end_unordered the four
  * _device encode / decode entry points above hand successive calls round-robin to `lanes` internal streams (1..4, 0 = the
- * default of 3), each launch with a share of the persistent workgroups: one batch's ramp-up and tail overlap its neighbours'
- * steady state (+4 % encode, +7 % decode on 20-frame 4K batches).  Ordering guarantees: everything enqueued on the context's
+ * default of 2): one batch's ramp-up and tail overlap its neighbour's steady state (+4 % encode, +6 % decode on 20-frame 4K
+ * batches, profiles/r03_layout_lab.txt).  Ordering guarantees: everything enqueued on the context's
  * stream before `begin` happens before every call of the section; everything enqueued after `end` happens after all of
  * them; calls inside the section that went to the same lane run in call order; nothing else is promised, so the calls of
  * one section must not depend on each other's output or write the same memory.  lumahip_sync inside a section waits for

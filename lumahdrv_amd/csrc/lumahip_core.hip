@@ -135,6 +135,8 @@ extern "C" int lumahip_reset_stream(lumahip_ctx *c)
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
+    if (c->lanes_active)
+        return fail(c, LUMAHIP_ERR_STATE, "close the unordered section before changing the stream");
     c->stream = c->own_stream;
     return LUMAHIP_OK;
 }
@@ -160,7 +162,7 @@ extern "C" int lumahip_begin_unordered(lumahip_ctx *c, int lanes)
     if (c->lanes_active)
         return fail(c, LUMAHIP_ERR_STATE, "lumahip_begin_unordered: a section is already open");
     if (lanes == 0)
-        lanes = c->lanes_default > 0 ? c->lanes_default : 3;
+        lanes = c->lanes_default > 0 ? c->lanes_default : 2;
     if (lanes < 1 || lanes > LUMAHIP_MAX_LANES)
         return fail(c, LUMAHIP_ERR_ARG, "lanes must be 1..%d (0 = default)", LUMAHIP_MAX_LANES);
     HIPCHK(c, hipSetDevice(c->device));
@@ -527,17 +529,12 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool f
     if (ycbcr && c->blocks_per_cu == 0 && threads == 512 && total_tiles >= 8L * c->num_cu * 18)
         per_cu = dir == 0 ? 18 : 12;
     long g = (long)c->num_cu * per_cu;
-    // Inside an unordered section `lanes_active` launches share the chip: each gets a share of the workgroups one launch
-    // would have -- more than 1/lanes of them, so that the chip stays full while a lane is between two launches
-    // (3 lanes: 4 per CU each for encode against 3 alone, 2.5 per CU each for decode against 5; r02_concurrent_launches.txt)
-    if (c->lanes_active > 1 && c->blocks_per_cu == 0 && threads == 256 && !ycbcr) {
-        if (c->lane_grid[dir] > 0)
-            g = c->lane_grid[dir];
-        else if (dir == 0 && per_cu == 3)
-            g = (long)c->num_cu * 12 / c->lanes_active;
-        else if (dir == 1 && per_cu == 5)
-            g = (long)c->num_cu * 15 / (2 * c->lanes_active);
-    }
+    // Inside an unordered section every launch keeps the grid it would have alone: two lanes of 3 (encode) / 5 (decode)
+    // workgroups per CU each measured best (profiles/r03_layout_lab.txt: encode 0.780 of the roofline against 0.751 ordered,
+    // 0.777 with 2 or 4 per CU each, 0.764 with three lanes; decode 0.760 against 0.715 ordered, 0.730 with 3.3 per CU each).
+    // lumahip_tune("lane_grid_enc" / "lane_grid_dec") overrides it for measurements.
+    if (c->lanes_active > 1 && c->lane_grid[dir] > 0)
+        g = c->lane_grid[dir];
     if (c->grid_override[dir] > 0)
         g = c->grid_override[dir];
     if (g > total_tiles)

@@ -150,7 +150,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr, cs_eff == CS_YCBCR);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, launch_stream(c), a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }

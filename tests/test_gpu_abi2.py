@@ -1,0 +1,282 @@
+"""ABI version 2 on a real MI355X: planar float frames, unordered sections, the decode traffic probe, the many-GPU layer
+(lumahip_multi_* from C++ and through ctypes), the copy threads of the host entry points.  Everything through the C ABI;
+the oracle is the checker."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFGS = {"pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0), "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0), "log12_xyz": (2, 12, 3, 8, 1e4, 0.005, 1.0)}
+
+
+def _ctx(L, cfg, torch):
+    ptf, bits, cs, bitsC, mx, mn, _ = cfg
+    c = L.Context(0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_quantizer(ptf, bits, cs, bitsC, mx, mn, L.build_lut(ptf, bits, mx, mn))
+    return c
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("profile", [2, 3])
+def test_planar_entry_points_equal_the_packed_ones(oracle_mod, name, profile):
+    """float frames as three colour-plane base pointers: channel-major (all R planes, all G planes, all B planes in three
+    separate buffers, frame stride w*h), frame-major with padding between the planes, and the packed LumaFrame layout itself --
+    identical planes / identical decoded floats to the packed entry points and to the oracle"""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    cfg = CFGS[name]
+    sc = cfg[6]
+    dev = torch.device("cuda:0")
+    ctx = _ctx(L, cfg, torch)
+    w, h, B = 200, 66, 5                       # w % 4 == 0, ragged against the 256-pixel tiles
+    n1, n3 = w * h, 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(B * n3, dtype=torch.float32, device=dev)
+    ctx.synth_frames_device(src.data_ptr(), n3, B, w, h, 11, 3)
+    planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, sc, profile, [p.data_ptr() for p in planes], st, psz)
+    out = torch.empty(B * n3, dtype=torch.float32, device=dev)
+    ctx.decode_frames_device([p.data_ptr() for p in planes], st, psz, B, w, h, profile, sc, out.data_ptr(), n3)
+    torch.cuda.synchronize()
+    s4 = src.view(B, 3, n1)
+    # (a) channel-major: three separate buffers
+    chan = [s4[:, k, :].contiguous() for k in range(3)]
+    pl_a = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.encode_frames_device_planar([c.data_ptr() for c in chan], n1, B, w, h, sc, profile, [p.data_ptr() for p in pl_a], st, psz)
+    out_a = [torch.full((B, n1), -7.0, dtype=torch.float32, device=dev) for _ in range(3)]
+    ctx.decode_frames_device_planar([p.data_ptr() for p in planes], st, psz, B, w, h, profile, sc, [c.data_ptr() for c in out_a], n1)
+    # (b) frame-major with 64 floats of padding behind every plane
+    pad = n1 + 64
+    fm = torch.zeros(B, 3, pad, dtype=torch.float32, device=dev)
+    fm[:, :, :n1] = s4
+    pl_b = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.encode_frames_device_planar([fm.data_ptr() + k * pad * 4 for k in range(3)], 3 * pad, B, w, h, sc, profile,
+                                    [p.data_ptr() for p in pl_b], st, psz)
+    # (c) the packed layout through the planar call
+    pl_c = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.encode_frames_device_planar([src.data_ptr() + k * n1 * 4 for k in range(3)], n3, B, w, h, sc, profile,
+                                    [p.data_ptr() for p in pl_c], st, psz)
+    torch.cuda.synchronize()
+    for other in (pl_a, pl_b, pl_c):
+        assert all(torch.equal(a, b) for a, b in zip(planes, other))
+    o4 = out.view(B, 3, n1)
+    for k in range(3):
+        assert torch.equal(out_a[k].view(torch.int32), o4[:, k, :].contiguous().view(torch.int32))
+    # against the oracle, frame 2
+    orc = o.Oracle(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5])
+    e, _, _ = orc.encode(o.synth_frame(w, h, 11, 3 + 2), sc, profile)
+    got = [pl_a[p][2 * psz[p]:3 * psz[p]].cpu().numpy().reshape(hs[p], st[p]) for p in range(3)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, e))
+    # overlapping planes are refused: G plane starting inside the R planes of a channel-major batch
+    with pytest.raises(L.LumaHipError):
+        ctx.encode_frames_device_planar([src.data_ptr(), src.data_ptr() + n1 * 4, src.data_ptr() + 2 * n1 * 4], n1, B, w, h, sc,
+                                        profile, [p.data_ptr() for p in pl_c], st, psz)
+    with pytest.raises(L.LumaHipError):
+        ctx.decode_frames_device_planar([p.data_ptr() for p in planes], st, psz, B, w, h, profile, sc,
+                                        [out.data_ptr(), out.data_ptr() + (n1 - 4) * 4, out.data_ptr() + 2 * n1 * 4], n3)
+    ctx.set_stream(None)
+    ctx.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_unordered_section_gives_the_ordered_results(oracle_mod, lanes):
+    """independent batches inside lumahip_begin_unordered / lumahip_end_unordered: same bytes as one stream; work queued on the
+    context's stream after `end` sees every batch; misuse is refused"""
+    import torch
+    import lumahdrv_amd as L
+    dev = torch.device("cuda:0")
+    cfg = CFGS["pq11_luv"]
+    ctx = _ctx(L, cfg, torch)
+    w, h, B, NB, profile = 1280, 720, 6, 7, 2
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(NB * B * n3, dtype=torch.float32, device=dev)
+    ctx.synth_frames_device(src.data_ptr(), n3, NB * B, w, h, 5, 0)
+
+    def run(section):
+        planes = [torch.zeros(NB * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        out = torch.zeros(NB * B * n3, dtype=torch.float32, device=dev)
+        if section:
+            ctx.begin_unordered(lanes)
+        for b in range(NB):
+            ctx.encode_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, 1.0, profile,
+                                     [planes[p].data_ptr() + b * B * psz[p] for p in range(3)], st, psz)
+        if section:
+            ctx.end_unordered()
+            ctx.begin_unordered(lanes)       # decode reads what the encode section wrote: a second section, after the first
+        for b in range(NB):
+            ctx.decode_frames_device([planes[p].data_ptr() + b * B * psz[p] for p in range(3)], st, psz, B, w, h, profile, 1.0,
+                                     out.data_ptr() + b * B * n3 * 4, n3)
+        if section:
+            ctx.end_unordered()
+        chk = out.sum(dtype=torch.float64)   # on torch's current stream = the context's stream: ordered after `end`
+        torch.cuda.synchronize()
+        return planes, out, float(chk)
+
+    p0, o0, c0 = run(False)
+    p1, o1, c1 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1)) and torch.equal(o0.view(torch.int32), o1.view(torch.int32)) and c0 == c1
+    # misuse
+    with pytest.raises(L.LumaHipError):
+        ctx.end_unordered()
+    ctx.begin_unordered(lanes)
+    with pytest.raises(L.LumaHipError):
+        ctx.begin_unordered(lanes)
+    with pytest.raises(L.LumaHipError):
+        ctx.set_stream(None)
+    ctx.sync()                               # legal inside a section
+    ctx.end_unordered()
+    with pytest.raises(L.LumaHipError):
+        ctx.begin_unordered(9)
+    ctx.set_stream(None)
+    ctx.close()
+
+
+def test_decode_traffic_probe_and_tuning_keys():
+    import torch
+    import lumahdrv_amd as L
+    dev = torch.device("cuda:0")
+    ctx = _ctx(L, CFGS["pq11_luv"], torch)
+    w, h, B = 1920, 1080, 4
+    n1, n3 = w * h, 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    psz = [hs[p] * st[p] for p in range(3)]
+    planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    out = torch.empty(B * n3, dtype=torch.float32, device=dev)
+    ms = ctx.probe_decode_traffic([p.data_ptr() for p in planes], st, psz, B, w, h, [out.data_ptr() + k * n1 * 4 for k in range(3)], n3, iters=3)
+    assert 0.0 < ms < 5.0
+    assert ctx.device() == 0
+    for key, val in (("block", 512), ("block", 0), ("blocks_per_cu", 4), ("blocks_per_cu", 0), ("grid_enc", 512), ("grid_enc", 0),
+                     ("lane_grid_dec", 640), ("lane_grid_dec", 0), ("copy_threads", 2), ("lanes", 2), ("lds_table_max_kb", -1)):
+        ctx.tune(key, val)
+    for key, val in (("block", 100), ("nonsense", 1), ("copy_threads", 99), ("lanes", 17)):
+        with pytest.raises(L.LumaHipError):
+            ctx.tune(key, val)
+    ctx.set_stream(None)
+    ctx.close()
+
+
+def test_search_index_is_lazy_and_cached():
+    """a context that only decodes never builds the encode-side search index; quantizer_info (or the first encode) does"""
+    import torch
+    import lumahdrv_amd as L
+    import time
+    lut = L.build_lut(L.PTF_PQ, 13)
+    c = L.Context(0)
+    t0 = time.perf_counter()
+    c.set_quantizer(L.PTF_PQ, 13, L.CS_LUV, 8, 1e4, 0.005, lut)
+    t_set = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    info = c.quantizer_info()
+    t_first = time.perf_counter() - t0
+    c2 = L.Context(0)
+    c2.set_quantizer(L.PTF_PQ, 13, L.CS_LUV, 8, 1e4, 0.005, lut)
+    t0 = time.perf_counter()
+    info2 = c2.quantizer_info()
+    t_cached = time.perf_counter() - t0
+    assert info == info2 and info["mode"] in (3, 4)
+    assert t_set < 0.5 * t_first or t_first < 0.02          # the table upload does not pay for the index
+    assert t_cached < 0.5 * t_first or t_first < 0.02       # the second context takes the index from the cache
+    c.close()
+    c2.close()
+
+
+@pytest.mark.parametrize("threads", [0, 1, 4, 7])
+def test_copy_threads_do_not_change_results(oracle_mod, threads):
+    """pageable host frames staged by 0 / 1 / 4 / 7 copy threads (odd split sizes, strides with padding)"""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    c = L.Context(0)
+    c.tune("copy_threads", threads)
+    c.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11))
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    w, h = 2562, 1442                          # 44 MB of floats: several 16 MiB staging chunks, odd row sizes
+    f = o.synth_frame(w, h, 3, 1)
+    for profile, align in ((2, 32), (3, 96)):
+        planes, st, _ = c.encode_frame(f, 1.0, profile, align=align)
+        e, st2, _ = orc.encode(f.copy(), 1.0, profile, align=align)
+        assert tuple(st2) == tuple(st) and all(np.array_equal(a, b) for a, b in zip(planes, e))
+        dec = c.decode_frame(planes, st, w, h, 1.0, profile)
+        assert np.array_equal(dec.view(np.uint32), orc.decode(e, st, w, h, 1.0, profile).view(np.uint32))
+    c.close()
+
+
+def _build_cpp(tmp, name):
+    exe = os.path.join(tmp, name)
+    lib = os.path.join(ROOT, "lumahdrv_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+                    "-o", exe, "-L" + lib, "-lluma_hip", "-llumahip", "-Wl,-rpath," + lib], check=True)
+    return exe
+
+
+def test_many_gpu_layer_from_cpp(tmp_path):
+    """tests/cpp/multi_batch.cpp: a 40-frame stream through lumahip_multi_* over all visible devices and over 2 / 3 logical
+    shards on device 0 (host batch, decode, device-resident), frame by frame equal to ONE context looping over the frames as
+    the reference's lumaenc does; the table reaches the devices through RCCL; LumaBatchEncoder -> stream -> LumaDecoder"""
+    exe = _build_cpp(str(tmp_path), "multi_batch")
+    r = subprocess.run([exe, "320", "180", "40", str(tmp_path / "batch.lhs")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "OK all" in r.stdout and "OK 3 shards on device 0" in r.stdout and "OK LumaBatchEncoder" in r.stdout
+    # ragged: fewer frames than shards
+    r = subprocess.run([exe, "64", "32", "2", str(tmp_path / "few.lhs")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK all" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_many_gpu_layer_through_ctypes_against_the_oracle(oracle_mod):
+    import torch
+    import lumahdrv_amd as L
+    from lumahdrv_amd import capi
+    o = oracle_mod
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if ndev > 1 else [0, 0, 0]
+    m = capi.Multi(devices)
+    assert m.shards == len(devices)
+    cfg = (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01)
+    m.set_quantizer(*cfg, L.build_lut(L.PTF_PQ, 10, 1000.0, 0.01))
+    assert m.used_rccl()
+    orc = o.Oracle(*cfg)
+    frames = [o.synth_frame(128, 64, 9, i) for i in range(7)]
+    planes, st, means = m.encode_frames(frames, 20.0, 2)
+    for f, pl in zip(frames, planes):
+        e, _, _ = orc.encode(f.copy(), 20.0, 2)
+        assert all(np.array_equal(a, b) for a, b in zip(pl, e))
+    dec = m.decode_frames(planes, st, 128, 64, 20.0, 2)
+    for pl, d in zip(planes, dec):
+        assert np.array_equal(d.view(np.uint32), orc.decode(pl, st, 128, 64, 20.0, 2).view(np.uint32))
+    # a second table through the same communicators
+    m.set_quantizer(L.PTF_LOG, 12, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_LOG, 12))
+    orc2 = o.Oracle(o.PTF_LOG, 12, o.CS_LUV, 8, 1e4, 0.005)
+    planes2, _, _ = m.encode_frames(frames[:3], 1.0, 2)
+    for f, pl in zip(frames, planes2):
+        assert all(np.array_equal(a, b) for a, b in zip(pl, orc2.encode(f.copy(), 1.0, 2)[0]))
+    assert m.ctx(0).quantizer_info()["mode"] == 3
+    m.close()
+
+
+def test_lumaenc_batch_mode_writes_the_same_stream(tmp_path):
+    """tools/lumaenc with LUMAENC_SHARDS (LumaBatchEncoder, what it uses by itself when several GPUs are visible) writes byte
+    for byte the stream the one-frame-at-a-time LumaEncoder loop writes"""
+    exe = os.path.join(ROOT, "lumahdrv_amd", "bin", "lumaenc")
+    a, b = str(tmp_path / "loop.lhs"), str(tmp_path / "batch.lhs")
+    base = [exe, "-i", "__test__", "-f", "1:7"]
+    env = dict(os.environ)
+    env.pop("LUMAENC_SHARDS", None)
+    import torch
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run(base + ["-o", a], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    else:
+        r = subprocess.run(base + ["-o", a], capture_output=True, text=True, env=dict(env, LUMAENC_SHARDS="1"), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(base + ["-o", b], capture_output=True, text=True, env=dict(env, LUMAENC_SHARDS="3", LUMAENC_FRAMES_PER_SHARD="1"),
+                       timeout=300)
+    assert r.returncode == 0 and "3 shard(s)" in r.stderr and "7 frames encoded" in r.stderr, r.stderr[-2000:]
+    assert open(a, "rb").read() == open(b, "rb").read()

@@ -129,3 +129,38 @@ def test_bench_never_mislabels_world_size():
     if not torch.cuda.is_available():
         q = _bench("--gpus", "2", "--steps", "1")
         assert q.returncode != 0 and "visible" in (q.stderr + q.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["torch", "multi"])
+def test_config5_full_size_stream(driver, oracle_mod, tmp_path):
+    """BASELINE configs[4] at FULL size on whatever GPUs this box has: the 2000-frame 3840x2160 PQ-11 Lu'v' stream, resident
+    (249 GB at N = 1), block-sharded, through bench.py's one-process-per-GPU driver and through the C ABI's many-GPU layer
+    (--driver multi).  The stream digest is independent of the driver and of N and equals the committed one
+    (profiles/r02_stream2000_n1.json); four frames are checked against the oracle's planes."""
+    import importlib.util
+    import torch
+    free = sum(torch.cuda.mem_get_info(d)[0] for d in range(torch.cuda.device_count()))
+    if free < 262e9:
+        pytest.skip("needs >= 262 GB of free HBM for the resident 2000-frame stream (have %.0f GB)" % (free / 1e9))
+    n = torch.cuda.device_count()
+    dump = str(tmp_path / "digests.json")
+    p = _bench("--gpus", str(n), "--stream-frames", "2000", "--driver", driver, "--min-seconds", "0.2", "--dump-digests", dump)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert r["n_gpus"] == n and r["digests"]["gathered_in_stream_order"] == 2000
+    assert r["digests"]["stream_digest"] == "54051a63ee9b1773"
+    assert r["value"] > 1e5
+    dig = json.load(open(dump))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    o = oracle_mod
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    w, h = 3840, 2160
+    for f in (0, 777, 1250, 1999):
+        planes, st, _ = orc.encode(o.synth_frame(w, h, b.SEED, f), 1.0, 2, threads=os.cpu_count() or 8)
+        t = [torch.from_numpy(np.ascontiguousarray(pl).reshape(-1)) for pl in planes]
+        psz = [int(x.numel()) for x in t]
+        want = int(b.frame_digests(t, psz, 1, torch.device("cpu"))[0].item()) & 0x7FFFFFFFFFFFFFFF
+        assert dig[f] == want, "frame %d of the stream differs from the oracle" % f

@@ -15,9 +15,12 @@ def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
     ctx = L.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
-    pool = HbmChunkPool(ctx, dev, n_float=3, n_y=1, n_uv=1)
+    pool = HbmChunkPool(ctx, dev, n_float=3, n_y=1, n_uv=1, n_striped=2)
     st_ = pool.stats
     assert st_["chunks"] >= 5 and len(pool.float) == 3 and len(pool.y) == 1 and len(pool.uv) == 1
+    assert [len(g) for g in pool.striped] == [2, 2, 2]
+    if st_["grouped"]:      # the striped chunks of list g really lie in region group g
+        assert all(pool.group_of(t) == g for g in range(3) for t in pool.striped[g])
     if st_["grouped"]:
         assert sum(st_["groups"]) == st_["chunks"] and len(st_["groups"]) >= 2
         pm = st_["probe_ms"]
