@@ -47,7 +47,7 @@ struct EncArgs {
     float sc;
     int bps;              // bytes per sample: 1 or 2
     int aligned;          // 1: vector stores allowed
-    float *stats;         // nullable: {sum,min,max} per frame
+    float *stats;         // nullable: per frame STATS_SLOTS partial {sum,min,max} triples (k_fold_stats folds them)
 };
 
 struct DecArgs {
@@ -302,14 +302,42 @@ struct EncStats {
     int frame;
 };
 
+// Per-frame statistics: every wave adds its partial {sum, min, max} with three atomics.  Thousands of waves on ONE triple
+// serialise at the L2 (a single 4K frame: 8192 waves, and the float min / max of the HIP headers are compare-and-swap loops
+// -- the kernel took 1.08 ms instead of 30 us, profiles/r03_hostfed_trace.txt), so the arrivals are spread over STATS_SLOTS
+// triples per frame (slot = workgroup index mod STATS_SLOTS) which k_fold_stats folds afterwards, and min / max use the
+// hardware's integer atomics on the float's bit pattern: for v >= 0 the signed-integer order of the bits is the float order,
+// for v < 0 the unsigned order is the reversed float order, and a negative float's bits exceed every non-negative one's as
+// unsigned and undercut them as signed -- so min(v) = v >= 0 ? atomicMin(int) : atomicMax(unsigned), and the mirror image
+// for max, are exact for any mix of signs starting from +inf / -inf.
+constexpr int STATS_SLOTS = 32;
+
+LH_DEV void atomic_min_f32(float *addr, float v)
+{
+    if (v >= 0.0f)
+        atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else
+        atomicMax(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+LH_DEV void atomic_max_f32(float *addr, float v)
+{
+    if (v >= 0.0f)
+        atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else
+        atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+
 LH_DEV void stats_flush(EncStats &st, float *stats, int tx)
 {
     if (st.frame >= 0) {
         const float s = wave_sum(st.sum), mn = wave_min(st.mn), mx = wave_max(st.mx);
         if (tx == 0) {
-            atomicAdd(&stats[3 * st.frame + 0], s);
-            atomicMin(&stats[3 * st.frame + 1], mn);
-            atomicMax(&stats[3 * st.frame + 2], mx);
+            float *p = stats + 3 * ((size_t)st.frame * STATS_SLOTS + (blockIdx.x & (STATS_SLOTS - 1)));
+            atomicAdd(p + 0, s);
+            if (mn == mn)   // (an all-NaN wave leaves +inf / -inf untouched, as fminf / fmaxf did within the wave)
+                atomic_min_f32(p + 1, mn);
+            if (mx == mx)
+                atomic_max_f32(p + 2, mx);
         }
     }
     st.sum = 0.0f;

@@ -67,7 +67,7 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_LDS_TABLE_MAX_KB", "lds_table_max_kb"},
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
-                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}};
+                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_COPY_SPIN", "copy_spin"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
                 (void)lumahip_tune(c, k[1], atol(e));
@@ -87,6 +87,7 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_stats_part);
     (void)hipFree(c->d_arr);
     for (auto &sl : c->slot) {
         (void)hipFree(sl.d_frame);
@@ -97,11 +98,17 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
         if (sl.d2h) (void)hipEventDestroy(sl.d2h);
     }
     if (c->h_stats) (void)hipHostFree(c->h_stats);
-    for (auto *st : {&c->stage_up[0], &c->stage_up[1], &c->stage_dn[0], &c->stage_dn[1]}) {
-        if (st->ev) (void)hipEventSynchronize(st->ev);
-        if (st->h) (void)hipHostFree(st->h);
-        if (st->ev) (void)hipEventDestroy(st->ev);
+    for (int i = 0; i < lumahip_ctx::MAX_BANDS; i++) {
+        if (c->band_h2d[i]) (void)hipEventDestroy(c->band_h2d[i]);
+        if (c->band_kern[i]) (void)hipEventDestroy(c->band_kern[i]);
     }
+    (void)hipFree(c->d_band_stats);
+    for (int i = 0; i < lumahip_ctx::N_STAGE; i++)
+        for (auto *st : {&c->stage_up[i], &c->stage_dn[i]}) {
+            if (st->ev) (void)hipEventSynchronize(st->ev);
+            if (st->h) (void)hipHostFree(st->h);
+            if (st->ev) (void)hipEventDestroy(st->ev);
+        }
     if (c->h_small) (void)hipHostFree(c->h_small);
     lumahip_copy_pool_destroy(c->copy_pool);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
@@ -238,6 +245,14 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->force_literal = v != 0;
         if (c->have_quant)
             return requantize(c);
+    } else if (k == "host_bands") {
+        if (v < 1 || v > lumahip_ctx::MAX_BANDS)
+            return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
+        c->host_bands = (int)v;
+    } else if (k == "copy_spin") {
+        c->copy_spin = v > 0 ? (int)std::min<long>(v, 10000000) : 0;
+        lumahip_copy_pool_destroy(c->copy_pool);
+        c->copy_pool = nullptr;
     } else if (k == "copy_threads") {
         if (v < 0 || v > 32)
             return fail(c, LUMAHIP_ERR_ARG, "copy_threads must be 0..32");
@@ -523,6 +538,10 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool f
     // memory system.  Short launches keep 8 per CU for their tail.
     if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 40L * c->num_cu * 3)
         per_cu = 3;
+    // ... and single frames with 4 per CU (profiles/r03_single_frame.txt: 1080p 12.7 against 13.2 us, 4K 28.2 against 30.0;
+    // 2 per CU is no better, and the decode kernels want their 8)
+    else if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && !ycbcr)
+        per_cu = 4;
     // The YCbCr kernels are VALU-bound and only three of their 512-thread workgroups (49 KiB of LDS each) are resident
     // per CU: many more, smaller static shares balance the CUs better than one share per resident workgroup -- 18 per CU
     // is 4.9 % faster than 4 for encode, 12 per CU 4.3 % for decode (same build in one process, profiles/r02_grid_sweep.txt).

@@ -66,13 +66,32 @@ static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
     return nullptr;
 }
 
-__global__ void k_init_stats(float *s, int nframes)
+// partial triples {0, +inf, -inf}: nframes * STATS_SLOTS of them
+__global__ void k_init_stats(float *s, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nframes) {
+    if (i < n) {
         s[3 * i + 0] = 0.0f;
         s[3 * i + 1] = __builtin_inff();
         s[3 * i + 2] = -__builtin_inff();
+    }
+}
+
+// fold the STATS_SLOTS partial triples of every frame into the caller's {sum, min, max}
+__global__ void k_fold_stats(const float *part, float *out, int nframes)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < nframes) {
+        float s = 0.0f, mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int k = 0; k < STATS_SLOTS; k++) {
+            const float *p = part + 3 * ((size_t)f * STATS_SLOTS + k);
+            s += p[0];
+            mn = fminf(mn, p[1]);
+            mx = fmaxf(mx, p[2]);
+        }
+        out[3 * f + 0] = s;
+        out[3 * f + 1] = mn;
+        out[3 * f + 2] = mx;
     }
 }
 
@@ -112,7 +131,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     a.frame_stride = frame_stride;
     a.sc = sc;
     a.bps = bps;
-    a.stats = stats;
+    a.stats = nullptr;
     a.aligned = 1;
     for (int p = 0; p < 3; p++) {
         if (!planes[p])
@@ -130,9 +149,27 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
     hipStream_t s = launch_stream(c);
-    if (stats)
-        hipLaunchKernelGGL(k_init_stats, dim3((nframes + 255) / 256), dim3(256), 0, s, stats, (int)nframes);
+    if (stats) {
+        // partial triples live in a context-owned scratch buffer; launches with statistics of one context share it, which is
+        // safe on one stream (in order) and is why an unordered section with statistics keeps to its first lane
+        const size_t need = (size_t)nframes * STATS_SLOTS * 3 * sizeof(float);
+        if (c->d_stats_part_cap < need) {
+            HIPCHK(c, hipDeviceSynchronize());
+            (void)hipFree(c->d_stats_part);
+            c->d_stats_part = nullptr;
+            c->d_stats_part_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_stats_part, need));
+            c->d_stats_part_cap = need;
+        }
+        if (c->lanes_active)
+            s = c->lane_stream[0];
+        a.stats = c->d_stats_part;
+        const int np = (int)nframes * STATS_SLOTS;
+        hipLaunchKernelGGL(k_init_stats, dim3((np + 255) / 256), dim3(256), 0, s, c->d_stats_part, np);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
+    if (stats)
+        hipLaunchKernelGGL(k_fold_stats, dim3((nframes + 63) / 64), dim3(64), 0, s, c->d_stats_part, stats, (int)nframes);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }

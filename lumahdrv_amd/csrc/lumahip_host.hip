@@ -2,6 +2,7 @@
 // pipeline of the batched forms.  No kernels here.
 #include "lumahip_internal.hpp"
 
+#include <atomic>
 #include <condition_variable>
 #include <thread>
 
@@ -14,9 +15,9 @@ using namespace lhost;
 // Pageable memory is NOT handed to hipMemcpy*Async: the runtime then pins the caller's pages on the fly and caches
 // that pinning, and on this stack (ROCm 7.2, MI355X) the GPU occasionally faulted on such a range when host buffers are
 // allocated and freed at a high rate ("Memory access fault by GPU ... on address <host heap page>", about one run of
-// the GPU test suite in twenty).  Pageable data therefore moves through two context-owned pinned chunks per direction:
-// the CPU copy of chunk k+1 overlaps the DMA of chunk k.
-static constexpr size_t XFER_CHUNK = (size_t)16 << 20;
+// the GPU test suite in twenty).  Pageable data therefore moves through a ring of context-owned pinned chunks per direction:
+// the CPU fills (empties) one chunk while the DMAs of the previous ones are in flight.
+static constexpr size_t XFER_CHUNK = (size_t)8 << 20;
 
 // ---- copy threads ---------------------------------------------------------------------------------------------------------
 // One CPU thread copies pageable memory into a pinned chunk at ~21 GB/s on the GPU box's host, a third of what the PCIe
@@ -29,13 +30,17 @@ struct lumahip_copy_pool {
         const unsigned char *src;
         size_t width, rows, dst_pitch, src_pitch;  // rows x width bytes; rows == 1: one flat span
     };
+    // A worker that has just finished a piece polls for the next one for ~0.5 ms before it goes to sleep on the condition
+    // variable: while a frame streams through, the pieces follow each other within tens of microseconds, and waking a
+    // sleeping thread costs 50-100 us on the GPU box's host -- as much as copying the piece (a 4K band is 8 MB).
+    int spin = 2000;
     std::vector<std::thread> workers;
     std::mutex mu;
-    std::condition_variable cv_go, cv_done;
+    std::condition_variable cv_go;
     std::vector<Job> jobs;     // one per worker for the current generation
-    unsigned generation = 0;
-    int pending = 0;
-    bool stop = false;
+    std::atomic<unsigned> generation{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
 
     explicit lumahip_copy_pool(int n)
     {
@@ -47,7 +52,7 @@ struct lumahip_copy_pool {
     {
         {
             std::lock_guard<std::mutex> lk(mu);
-            stop = true;
+            stop.store(true);
         }
         cv_go.notify_all();
         for (auto &t : workers)
@@ -66,22 +71,23 @@ struct lumahip_copy_pool {
     {
         unsigned seen = 0;
         for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_go.wait(lk, [&] { return stop || generation != seen; });
-                if (stop)
+            int spins = 0;
+            unsigned g;
+            while ((g = generation.load(std::memory_order_acquire)) == seen) {
+                if (stop.load(std::memory_order_relaxed))
                     return;
-                seen = generation;
-                j = jobs[me];
+                if (++spins < spin) {
+                    __builtin_ia32_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop.load() || generation.load() != seen; });
             }
+            seen = g;
+            const Job j = jobs[me];
             if (j.width)
                 run(j);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0)
-                    cv_done.notify_one();
-            }
+            pending.fetch_sub(1, std::memory_order_release);
         }
     }
     // rows x width bytes from src (pitch sp) to dst (pitch dp), split over the workers and the calling thread
@@ -90,7 +96,7 @@ struct lumahip_copy_pool {
         const size_t parts = workers.size() + 1;
         const bool flat = rows == 1;
         const size_t total = flat ? width : rows;
-        if (total * (flat ? 1 : width) < ((size_t)1 << 20) || total < parts) {  // small: not worth waking anyone
+        if (total * (flat ? 1 : width) < ((size_t)256 << 10) || total < parts) {  // small: not worth handing out
             run(Job{dst, src, width, rows, dp, sp});
             return;
         }
@@ -104,19 +110,19 @@ struct lumahip_copy_pool {
                 return Job{nullptr, nullptr, 0, 0, 0, 0};
             return flat ? Job{dst + a, src + a, b - a, 1, 0, 0} : Job{dst + a * dp, src + a * sp, width, b - a, dp, sp};
         };
+        for (size_t k = 0; k < workers.size(); k++)
+            jobs[k] = part(k + 1);
+        pending.store((int)workers.size(), std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> lk(mu);
-            for (size_t k = 0; k < workers.size(); k++)
-                jobs[k] = part(k + 1);
-            pending = (int)workers.size();
-            generation++;
+            std::lock_guard<std::mutex> lk(mu);   // (a worker about to sleep re-checks the generation under this lock)
+            generation.fetch_add(1, std::memory_order_release);
         }
         cv_go.notify_all();
         const Job mine = part(0);
         if (mine.width)
             run(mine);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
+        while (pending.load(std::memory_order_acquire) != 0)
+            __builtin_ia32_pause();
     }
 };
 
@@ -124,8 +130,10 @@ void lumahip_copy_pool_destroy(lumahip_copy_pool *p) { delete p; }
 
 static void staged_copy(lumahip_ctx *c, unsigned char *dst, size_t dp, const unsigned char *src, size_t sp, size_t width, size_t rows)
 {
-    if (c->copy_threads > 0 && !c->copy_pool)
+    if (c->copy_threads > 0 && !c->copy_pool) {
         c->copy_pool = new lumahip_copy_pool(c->copy_threads);
+        c->copy_pool->spin = c->copy_spin;
+    }
     if (c->copy_pool)
         c->copy_pool->copy(dst, dp, src, sp, width, rows);
     else
@@ -159,6 +167,22 @@ static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
     if (st.pending) {
         HIPCHK(c, hipEventSynchronize(st.ev));
         st.pending = false;
+        if (st.out) {   // a device -> host chunk: its DMA has landed, hand the bytes to the caller's memory
+            staged_copy(c, st.out, st.out_pitch, st.h, st.chunk_pitch, st.width, st.rows);
+            st.out = nullptr;
+        }
+    }
+    return LUMAHIP_OK;
+}
+
+// every device -> host chunk still in flight: wait for it and copy it out (oldest first)
+static int d2h_flush(lumahip_ctx *c)
+{
+    for (int i = 0; i < lumahip_ctx::N_STAGE; i++) {
+        lumahip_ctx::Stage &st = c->stage_dn[(c->dn_next + i) % lumahip_ctx::N_STAGE];
+        if (st.h && st.pending)
+            if (int rc = stage_ready(c, st))
+                return rc;
     }
     return LUMAHIP_OK;
 }
@@ -183,9 +207,8 @@ static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, si
         return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
     const size_t total = flat ? width * rows : rows;                 // bytes or rows
     const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;          // per chunk
-    int k = 0;
-    for (size_t done = 0; done < total; k++) {
-        lumahip_ctx::Stage &st = c->stage_up[k & 1];
+    for (size_t done = 0; done < total;) {
+        lumahip_ctx::Stage &st = c->stage_up[c->up_next++ % lumahip_ctx::N_STAGE];
         int rc = stage_ready(c, st);
         if (rc)
             return rc;
@@ -215,9 +238,12 @@ int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream
 
 }
 
-// Device -> host.  Pinned destination: queued on `s`, the caller synchronises.  Pageable destination: the data is in
-// `dst` when the call returns (everything queued on `s` before it has completed by then).
-static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, size_t dp, size_t width, size_t rows, hipStream_t s)
+// Device -> host.  Pinned destination: queued on `s`, the caller synchronises.  Pageable destination: the data goes through
+// the ring of pinned chunks; with `deferred` false it is in `dst` when the call returns (everything queued on `s` before it has
+// completed by then), with `deferred` true the last chunks may still be in flight and d2h_flush() completes them -- which lets
+// the DMA of one piece overlap the copy-out of the previous one ACROSS calls (the row bands of the host entry points).
+static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, size_t dp, size_t width, size_t rows, hipStream_t s,
+                       bool deferred = false)
 {
     if (!width || !rows)
         return LUMAHIP_OK;
@@ -233,20 +259,9 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
         return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
     const size_t total = flat ? width * rows : rows;
     const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;
-    size_t prev_done = 0, prev_n = 0;
-    int k = 0;
-    auto drain = [&](lumahip_ctx::Stage &st, size_t at, size_t n) -> int {
-        HIPCHK(c, hipEventSynchronize(st.ev));
-        st.pending = false;
-        if (flat)
-            staged_copy(c, (unsigned char *)dst + at, 0, st.h, 0, n, 1);
-        else
-            staged_copy(c, (unsigned char *)dst + at * hp, hp, st.h, dp, width, n);
-        return LUMAHIP_OK;
-    };
-    for (size_t done = 0; done < total; k++) {
-        lumahip_ctx::Stage &st = c->stage_dn[k & 1];
-        int rc = stage_ready(c, st);
+    for (size_t done = 0; done < total;) {
+        lumahip_ctx::Stage &st = c->stage_dn[c->dn_next++ % lumahip_ctx::N_STAGE];
+        int rc = stage_ready(c, st);   // completes (copies out) the chunk this ring slot carried N_STAGE chunks ago
         if (rc)
             return rc;
         const size_t n = total - done < per ? total - done : per;
@@ -254,13 +269,21 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
         HIPCHK(c, hipMemcpyAsync(st.h, (const unsigned char *)src + done * (flat ? 1 : dp), bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(st.ev, s));
         st.pending = true;
-        if (k > 0 && (rc = drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n)))
-            return rc;
-        prev_done = done;
-        prev_n = n;
+        if (flat) {
+            st.out = (unsigned char *)dst + done;
+            st.out_pitch = st.chunk_pitch = 0;
+            st.width = n;
+            st.rows = 1;
+        } else {
+            st.out = (unsigned char *)dst + done * hp;
+            st.out_pitch = hp;
+            st.chunk_pitch = dp;
+            st.width = width;
+            st.rows = n;
+        }
         done += n;
     }
-    return drain(c->stage_dn[(k - 1) & 1], prev_done, prev_n);
+    return deferred ? LUMAHIP_OK : d2h_flush(c);
 }
 
 namespace lhost {
@@ -268,6 +291,11 @@ namespace lhost {
 int xfer_d2h(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     return xfer_d2h_2d(c, dst, bytes, src, bytes, bytes, 1, s);
+}
+
+static int xfer_d2h_deferred(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    return xfer_d2h_2d(c, dst, bytes, src, bytes, bytes, 1, s, true);
 }
 
 // a few floats from the device: through the pinned scratch, synchronous
@@ -327,6 +355,38 @@ static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, co
 // replace the statistic by the reference's exact value (k_seq_sum), outside it the decision is the same either way.
 static bool mean_near_threshold(float m) { return m >= 0.25f && m <= 4.0f; }
 
+static int pipe_streams(lumahip_ctx *c);
+
+// ---- row bands ------------------------------------------------------------------------------------------------------------
+// One host frame per call is PCIe time: 99.5 MB up at ~56 GB/s (1.76 ms), 30 us of kernel, 24.9 MB down (0.45 ms); done one
+// after the other that is 2.2 ms pinned and more staged (profiles/r03_hostfed_lab.txt).  Rows are independent (pairs of rows
+// in 4:2:0), so a large frame is cut into `host_bands` bands of rows: band k+1 goes up while band k is transformed and band
+// k-1 comes down -- the link is full duplex -- and the call is bound by the larger of the two directions.  Bands are whole
+// tiles of the kernels (multiples of 8 rows), so every pixel sees exactly the arithmetic of the unbanded launch.
+static int band_rows(const lumahip_ctx *c, unsigned w, unsigned h, int &nb)
+{
+    nb = c->host_bands;
+    if ((size_t)w * h < (size_t)1 << 20 || nb < 2)      // small frames: latency, not bandwidth
+        nb = 1;
+    int hb = (int)(((h + nb - 1) / nb + 7) & ~7u);
+    if (hb < 64)
+        hb = 64;
+    nb = (int)((h + hb - 1) / hb);
+    return hb;
+}
+
+static int band_events(lumahip_ctx *c, int nb)
+{
+    for (int k = 0; k < nb; k++)
+        if (!c->band_h2d[k]) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->band_h2d[k], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->band_kern[k], hipEventDisableTiming));
+        }
+    if (!c->d_band_stats)
+        HIPCHK(c, hipMalloc(&c->d_band_stats, lumahip_ctx::MAX_BANDS * 3 * sizeof(float)));
+    return LUMAHIP_OK;
+}
+
 static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
                                   unsigned char *const planes[3], const int stride[3], float *mean_lum,
                                   float *transformed_out, int cs_eff)
@@ -351,19 +411,79 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         return rc;
     if (!c->d_stats)
         HIPCHK(c, hipMalloc(&c->d_stats, 3 * sizeof(float)));
-    if ((rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
-        return rc;
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
     const size_t pfs[3] = {0, 0, 0};
-    {
-        const float *const fp[3] = {c->d_frame, c->d_frame + nfl / 3, c->d_frame + 2 * (nfl / 3)};
-        rc = encode_frames_device_impl(c, fp, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff);
-    }
-    if (rc)
-        return rc;
-    for (int p = 0; p < 3; p++)
-        if ((rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+    const size_t n1 = (size_t)w * h;
+    const bool sub = (profile == 0 || profile == 2);
+    int nb = 1;
+    const int hb = band_rows(c, w, h, nb);
+    float st[3] = {0.0f, __builtin_inff(), -__builtin_inff()};
+    if (nb > 1) {
+        if ((rc = pipe_streams(c)) || (rc = band_events(c, nb)))
             return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the bands run on the pipeline streams: after everything queued so far
+        hipStream_t saved = c->stream;
+        auto fetch = [&](int k) -> int {              // planes rows of band k, after its kernel
+            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            HIPCHK(c, hipStreamWaitEvent(c->s_d2h, c->band_kern[k], 0));
+            for (int p = 0; p < 3; p++) {
+                const unsigned pr0 = (p && sub) ? r0 / 2 : r0, prow = (p && sub) ? rows / 2 : rows;
+                const size_t off = (size_t)pr0 * stride[p];
+                if (int r = xfer_d2h_2d(c, planes[p] + off, stride[p], dp[p] + off, stride[p], L.row_bytes[p], prow, c->s_d2h, true))
+                    return r;
+            }
+            return LUMAHIP_OK;
+        };
+        for (int k = 0; k < nb && rc == LUMAHIP_OK; k++) {
+            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const size_t roff = (size_t)r0 * w;
+            for (int ch = 0; ch < 3 && rc == LUMAHIP_OK; ch++)
+                rc = xfer_h2d(c, c->d_frame + ch * n1 + roff, rgb + ch * n1 + roff, (size_t)rows * w * sizeof(float), c->s_h2d);
+            if (rc)
+                break;
+            HIPCHK(c, hipEventRecord(c->band_h2d[k], c->s_h2d));
+            HIPCHK(c, hipStreamWaitEvent(c->s_kern, c->band_h2d[k], 0));
+            const float *const fp[3] = {c->d_frame + roff, c->d_frame + n1 + roff, c->d_frame + 2 * n1 + roff};
+            unsigned char *bp[3];
+            for (int p = 0; p < 3; p++)
+                bp[p] = dp[p] + (size_t)((p && sub) ? r0 / 2 : r0) * stride[p];
+            c->stream = c->s_kern;
+            rc = encode_frames_device_impl(c, fp, nfl, 1, w, rows, sc, profile, bp, stride, pfs, c->d_band_stats + 3 * k, cs_eff);
+            c->stream = saved;
+            if (rc)
+                break;
+            HIPCHK(c, hipEventRecord(c->band_kern[k], c->s_kern));
+            if (k >= 1)
+                rc = fetch(k - 1);
+        }
+        if (rc == LUMAHIP_OK)
+            rc = fetch(nb - 1);
+        if (int r = d2h_flush(c))   // the chunks still in flight (also after an error: nothing may stay pending)
+            rc = rc ? rc : r;
+        c->stream = saved;
+        HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+        HIPCHK(c, hipStreamSynchronize(c->s_kern));
+        HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+        if (rc)
+            return rc;
+        float bs[lumahip_ctx::MAX_BANDS * 3];
+        if ((rc = read_small(c, bs, c->d_band_stats, 3 * nb, c->stream)))
+            return rc;
+        for (int k = 0; k < nb; k++) {
+            st[0] += bs[3 * k];
+            st[1] = fminf(st[1], bs[3 * k + 1]);
+            st[2] = fmaxf(st[2], bs[3 * k + 2]);
+        }
+    } else {
+        if ((rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
+            return rc;
+        const float *const fp[3] = {c->d_frame, c->d_frame + n1, c->d_frame + 2 * n1};
+        if ((rc = encode_frames_device_impl(c, fp, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff)))
+            return rc;
+        for (int p = 0; p < 3; p++)
+            if ((rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
+                return rc;
+    }
     if (transformed_out) {
         rc = lumahip_transform_color_space_device(c, c->d_frame, nfl, 1, w, h, 1, sc);
         if (rc)
@@ -371,9 +491,10 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         if ((rc = xfer_d2h(c, transformed_out, c->d_frame, nfl * sizeof(float), c->stream)))
             return rc;
     }
-    float st[3] = {0, 0, 0};
-    if ((rc = read_small(c, st, c->d_stats, 3, c->stream)))  // synchronises the stream
+    if (nb == 1 && (rc = read_small(c, st, c->d_stats, 3, c->stream)))  // synchronises the stream
         return rc;
+    if (transformed_out)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mean_lum) {
         *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
         if (mean_near_threshold(*mean_lum))  // d_frame holds the caller's frame, or already its transformed version
@@ -412,12 +533,64 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
     if ((rc = ensure(c, (void **)&c->d_planes, &c->d_planes_cap, L.total)))
         return rc;
     unsigned char *dp[3] = {c->d_planes + L.off[0], c->d_planes + L.off[1], c->d_planes + L.off[2]};
+    const size_t pfs[3] = {0, 0, 0};
+    const size_t n1 = (size_t)w * h;
+    const bool sub = (profile == 0 || profile == 2);
+    int nb = 1;
+    const int hb = band_rows(c, w, h, nb);
+    if (nb > 1) {
+        if ((rc = pipe_streams(c)) || (rc = band_events(c, nb)))
+            return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipStream_t saved = c->stream;
+        auto fetch = [&](int k) -> int {              // float rows of band k, after its kernel
+            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const size_t roff = (size_t)r0 * w;
+            HIPCHK(c, hipStreamWaitEvent(c->s_d2h, c->band_kern[k], 0));
+            for (int ch = 0; ch < 3; ch++)
+                if (int r = xfer_d2h_deferred(c, rgb_out + ch * n1 + roff, c->d_frame + ch * n1 + roff, (size_t)rows * w * sizeof(float), c->s_d2h))
+                    return r;
+            return LUMAHIP_OK;
+        };
+        for (int k = 0; k < nb && rc == LUMAHIP_OK; k++) {
+            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const size_t roff = (size_t)r0 * w;
+            const unsigned char *bp[3];
+            for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++) {
+                const unsigned pr0 = (p && sub) ? r0 / 2 : r0, prow = (p && sub) ? rows / 2 : rows;
+                const size_t off = (size_t)pr0 * stride[p];
+                bp[p] = dp[p] + off;
+                rc = xfer_h2d_2d(c, dp[p] + off, stride[p], planes[p] + off, stride[p], L.row_bytes[p], prow, c->s_h2d);
+            }
+            if (rc)
+                break;
+            HIPCHK(c, hipEventRecord(c->band_h2d[k], c->s_h2d));
+            HIPCHK(c, hipStreamWaitEvent(c->s_kern, c->band_h2d[k], 0));
+            float *const fp[3] = {c->d_frame + roff, c->d_frame + n1 + roff, c->d_frame + 2 * n1 + roff};
+            c->stream = c->s_kern;
+            rc = decode_impl(c, bp, stride, pfs, 1, w, rows, profile, sc, fp, nfl, DisplayParams(), cs_eff);
+            c->stream = saved;
+            if (rc)
+                break;
+            HIPCHK(c, hipEventRecord(c->band_kern[k], c->s_kern));
+            if (k >= 1)
+                rc = fetch(k - 1);
+        }
+        if (rc == LUMAHIP_OK)
+            rc = fetch(nb - 1);
+        if (int r = d2h_flush(c))   // the chunks still in flight (also after an error: nothing may stay pending)
+            rc = rc ? rc : r;
+        c->stream = saved;
+        HIPCHK(c, hipStreamSynchronize(c->s_h2d));
+        HIPCHK(c, hipStreamSynchronize(c->s_kern));
+        HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+        return rc;
+    }
     for (int p = 0; p < 3; p++)
         if ((rc = xfer_h2d_2d(c, dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
             return rc;
-    const size_t pfs[3] = {0, 0, 0};
     {
-        float *const fp[3] = {c->d_frame, c->d_frame + nfl / 3, c->d_frame + 2 * (nfl / 3)};
+        float *const fp[3] = {c->d_frame, c->d_frame + n1, c->d_frame + 2 * n1};
         rc = decode_impl(c, dp, stride, pfs, 1, w, h, profile, sc, fp, nfl, DisplayParams(), cs_eff);
     }
     if (rc)
@@ -439,12 +612,21 @@ extern "C" int lumahip_decode_frame_host(lumahip_ctx *c, const unsigned char *co
 // ---- batched host entry points: a 3-slot software pipeline over three streams.  Frame i's H2D copy runs while
 // frame i-1's kernel and frame i-2's D2H copies are in flight; with pinned caller memory (lumahip_host_register) the
 // two copy directions overlap as well and the rate approaches the PCIe H2D rate.
-static int pipe_prepare(lumahip_ctx *c, size_t frame_bytes, size_t planes_bytes, unsigned nframes)
+static int pipe_streams(lumahip_ctx *c)
 {
     if (!c->s_h2d) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_kern, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    }
+    return LUMAHIP_OK;
+}
+
+static int pipe_prepare(lumahip_ctx *c, size_t frame_bytes, size_t planes_bytes, unsigned nframes)
+{
+    if (int rc = pipe_streams(c))
+        return rc;
+    if (!c->slot[0].h2d) {
         for (auto &sl : c->slot) {
             HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&sl.kern, hipEventDisableTiming));

@@ -61,6 +61,8 @@ struct lumahip_ctx {
     unsigned char *d_planes = nullptr;
     size_t d_planes_cap = 0;
     float *d_stats = nullptr;
+    float *d_stats_part = nullptr;   // partial statistics triples of the encode kernels (STATS_SLOTS per frame)
+    size_t d_stats_part_cap = 0;
     float *d_arr = nullptr;
     size_t d_arr_cap = 0;
 
@@ -74,6 +76,11 @@ struct lumahip_ctx {
     size_t slot_frame_cap = 0, slot_planes_cap = 0;
     hipStream_t s_h2d = nullptr, s_kern = nullptr, s_d2h = nullptr;
     float *h_stats = nullptr;  // pinned, 3 floats per frame
+    // row bands of the single-frame host entry points (H2D of band k+1 | kernel of band k | D2H of band k-1)
+    static constexpr int MAX_BANDS = 8;
+    hipEvent_t band_h2d[MAX_BANDS] = {}, band_kern[MAX_BANDS] = {};
+    float *d_band_stats = nullptr;  // 3 floats per band
+    int host_bands = 4;             // lumahip_tune("host_bands"): 1 = the whole frame in one piece
     size_t h_stats_cap = 0;
 
     // Pinned staging for pageable caller memory (see xfer_h2d): two chunks per direction, ping-pong
@@ -81,10 +88,17 @@ struct lumahip_ctx {
         unsigned char *h = nullptr;
         hipEvent_t ev = nullptr;
         bool pending = false;  // a DMA that reads / writes this chunk may still be in flight
-    } stage_up[2], stage_dn[2];
+        // device -> host only: what to do with the chunk once its DMA has landed (copy it out to the caller's pageable memory)
+        unsigned char *out = nullptr;
+        size_t out_pitch = 0, chunk_pitch = 0, width = 0, rows = 0;
+    };
+    static constexpr int N_STAGE = 4;   // chunks per direction: up to four DMAs queued while the CPU fills / empties the next
+    Stage stage_up[N_STAGE], stage_dn[N_STAGE];
+    unsigned up_next = 0, dn_next = 0;  // ring positions
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
     lumahip_copy_pool *copy_pool = nullptr;
-    int copy_threads = 4;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)
+    int copy_threads = 3;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)
+    int copy_spin = 2000;      // lumahip_tune("copy_spin"): polls of an idle worker before it sleeps
 
     int block_threads = 256;
     bool block_forced = false;
