@@ -76,9 +76,10 @@ int lumahip_sync(lumahip_ctx *ctx);
  * count of lumahip_begin_unordered), "lane_grid_enc" / "lane_grid_dec" (workgroups per launch inside an unordered section,
  * 0 = rule), "copy_threads" (worker threads that copy pageable caller memory into the pinned staging chunks of the _host
  * entry points: 0..32, default 3), "host_bands" (row bands the single-frame _host entry points split a frame into so that
- * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
+ * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "ycbcr_tables" (0: the
+ * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
  * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
- * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS set the
+ * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_YCBCR_TABLES set the
  * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
 int lumahip_tune(lumahip_ctx *ctx, const char *key, long value);
 
@@ -107,6 +108,15 @@ int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, fl
  * decreasing or duplicate entries, too many records) and the kernels run the literal bisection instead.
  * rec_out (nullable, rec_cap entries) receives the records. */
 int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
+
+/* Host-only (no GPU, no context): the two per-stream tables of the YCbCr kernels, built with the host libm as the reference
+ * would evaluate them per pixel.  (1) The threshold records -- same format and lookup as lumahip_thresh_index_host, for
+ * arguments t >= +0 or NaN -- of the composite function  t -> quantize(PQdec(t / 255), 0)  with t = 219 y + 16, y the pixel's luma
+ * (src/luma_quantizer.cpp:337, 496-500, 222-235), from which the encode kernels take a pixel's luminance code.
+ * (2) out[i] = (255 PQenc(lut[i]) - 16) / 219 (src/luma_quantizer.cpp:447-448, 491-494), which the decode kernels read
+ * instead of evaluating PQenc per pixel. */
+int lumahip_ycbcr_luma_index_host(const float *lut, size_t n, float maxLum, int info[5], uint32_t *rec_out, size_t rec_cap);
+int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float maxLum, float *out);
 
 /* introspection of the search index built for the current LUT (tests):
  * info[0] = mode (0 = literal bisection, table in LDS; 2 = literal bisection, table read from global memory
@@ -252,6 +262,13 @@ int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t 
  * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the
  * device function with the host libm exhaustively. */
 int lumahip_powf_probe_device(lumahip_ctx *ctx, float *out_dev, uint32_t first_bits, size_t n, float y, int regular);
+
+/* Test probe (YCbCr quantizers): out[i] = the luminance code of a pixel whose t = 219 y + 16 (y = its luma,
+ * src/luma_quantizer.cpp:335-337) is the float with bit pattern first_bits + i.  direct = 0: through the composite threshold
+ * records exactly as the encode kernels read them; direct = 1: the reference's arithmetic, PQdec(t / 255) then LumaQuantizer::quantize(., 0)
+ * (src/luma_quantizer.cpp:337, 496-500, 222-235), evaluated on the device with the complete powf and IEEE division.
+ * n % 4 == 0.  LUMAHIP_ERR_UNSUPPORTED when the table has no composite records. */
+int lumahip_ycbcr_luma_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int direct);
 
 /* Pin caller-owned host memory (hipHostRegister) so that the _host entry points DMA it at PCIe rate instead
  * of going through the runtime's pageable staging path.  Optional; unregister before freeing the memory. */

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_quantizer_info",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device", "lumahip_mean_luminance_reference_device",
@@ -32,7 +32,7 @@ SYMBOLS = [
     "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl",
     "lumahip_shard_range", "lumahip_multi_set_quantizer", "lumahip_multi_encode_frames_host", "lumahip_multi_decode_frames_host",
     "lumahip_multi_encode_frames_device", "lumahip_multi_decode_frames_device", "lumahip_multi_sync",
-    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_quantize_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
+    "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_quantize_probe_device", "lumahip_ycbcr_luma_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
 ]
 
 
@@ -118,6 +118,8 @@ def lib():
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
     L.lumahip_thresh_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
+    L.lumahip_ycbcr_luma_index_host.argtypes = [vp, sz, f, C.POINTER(i), vp, sz]
+    L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
     L.lumahip_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
@@ -139,6 +141,7 @@ def lib():
     L.lumahip_probe_encode_traffic_device.argtypes = [vp, vp, sz, u, u, u, pp3, ip3, sp3, i, C.POINTER(f)]
     L.lumahip_powf_probe_device.argtypes = [vp, vp, C.c_uint32, sz, f, i]
     L.lumahip_quantize_probe_device.argtypes = [vp, vp, C.c_uint32, sz, i]
+    L.lumahip_ycbcr_luma_probe_device.argtypes = [vp, vp, C.c_uint32, sz, i]
     L.lumahip_host_register.argtypes = [vp, vp, sz]
     L.lumahip_host_unregister.argtypes = [vp, vp]
     L.lumahip_malloc.argtypes = [vp, C.POINTER(vp), sz]
@@ -248,6 +251,33 @@ def thresh_index(lut: np.ndarray):
             raise LumaHipError(rc, "lumahip_thresh_index_host failed")
         d["rec"] = rec
     return d
+
+
+def ycbcr_luma_index(lut: np.ndarray, max_lum: float):
+    """host-only: the composite luma -> luminance code records of the YCbCr encode kernels (same dict as thresh_index)"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    info = (C.c_int * 5)()
+    rc = lib().lumahip_ycbcr_luma_index_host(lut.ctypes.data, lut.size, max_lum, info, None, 0)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_ycbcr_luma_index_host failed")
+    d = dict(ok=bool(info[0]), mant_bits=info[1], shift=info[2], kmin=info[3], nbuckets=info[4], rec=None)
+    if d["ok"]:
+        rec = np.zeros(info[4], dtype=np.uint32)
+        rc = lib().lumahip_ycbcr_luma_index_host(lut.ctypes.data, lut.size, max_lum, info, rec.ctypes.data, rec.size)
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_ycbcr_luma_index_host failed")
+        d["rec"] = rec
+    return d
+
+
+def ycbcr_ytab(lut: np.ndarray, max_lum: float) -> np.ndarray:
+    """host-only: the per-stream y table of the YCbCr decode kernels"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    out = np.empty_like(lut)
+    rc = lib().lumahip_ycbcr_ytab_host(lut.ctypes.data, lut.size, max_lum, out.ctypes.data)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_ycbcr_ytab_host failed")
+    return out
 
 
 def thresh_lookup(ix, v: np.ndarray) -> np.ndarray:
@@ -498,6 +528,11 @@ class Context:
     def quantize_probe_device(self, out_ptr, first_bits, n, nonneg=False):
         """uint16 codes of the n consecutive fp32 bit patterns from first_bits, through quantize_lut<mode, 4, nonneg>"""
         self._chk(self.L.lumahip_quantize_probe_device(self.h, out_ptr, first_bits, n, int(bool(nonneg))))
+
+    def ycbcr_luma_probe_device(self, out_ptr, first_bits, n, direct=False):
+        """uint16 luminance codes of the n consecutive fp32 luma bit patterns from first_bits (YCbCr quantizers): through the
+        composite records (direct=False) or through the reference's arithmetic on the device (direct=True)"""
+        self._chk(self.L.lumahip_ycbcr_luma_probe_device(self.h, out_ptr, first_bits, n, int(bool(direct))))
 
     def host_register(self, arr: np.ndarray):
         """pin a numpy array's memory for PCIe-rate transfers by the host entry points"""

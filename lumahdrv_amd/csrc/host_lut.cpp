@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/lumahip.h"
+#include "host_lut.hpp"
+#include "lut_index.hpp"
 
 namespace {
 
@@ -25,6 +27,14 @@ float pq_decode_host(float L, float val)
     const float m = 78.8438, n = 0.1593, c1 = 0.8359, c2 = 18.8516, c3 = 18.6875;
     float Vp = powf(val, 1.0f / m);
     return L * powf(std::max(0.0f, (Vp - c1)) / (c2 - c3 * Vp), 1.0f / n);
+}
+
+// LumaQuantizer::transformPQ, encode branch (src/luma_quantizer.cpp:491-494)
+float pq_encode_host(float L, float val)
+{
+    const float m = 78.8438, n = 0.1593, c1 = 0.8359, c2 = 18.8516, c3 = 18.6875;
+    float Lp = powf(val / L, n);
+    return powf((c1 + c2 * Lp) / (1 + c3 * Lp), m);
 }
 
 // LumaQuantizer::transformLog, decode branch (src/luma_quantizer.cpp:509)
@@ -96,3 +106,32 @@ extern "C" int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float
     }
     }
 }
+
+// ---- the two per-stream tables of the YCbCr kernels (luma_device.hpp: ycbcr_fwd / ycbcr_inv), built with the host libm -- the
+// very function the reference calls -- once per stream instead of two powf per pixel on the device.
+namespace lh {
+
+// Encode side: the luminance code the reference gives a pixel as a function of t = 219 y + 16, the numerator of
+// src/luma_quantizer.cpp:337 (y = the pixel's luma): code(t) = search(PQdec(t / 255)), PQdec = :496-500, search = :222-235.
+// (Keyed by t rather than y because the codes are roughly uniform in t -- four binary octaves, 16 ... 256, hold every
+// threshold, so the records are a few KiB; keyed by y they span eleven octaves and 46 KiB.)
+// The luma is a sum of non-negative products, so t >= 16 (or NaN) in the kernels; below 16 the function is continued as a
+// constant, which keeps the thresholds of the never-used codes below code(16) -- spread over dozens of octaves -- out of the records.
+int ycbcr_luma_code_host(float t, const float *lut, int maxVal, float Lmax)
+{
+    if (t < 16.0f)
+        t = 16.0f;
+    const float c0 = pq_decode_host(Lmax, t / 255.0f);
+    return quantize_literal_host(c0, lut, maxVal);
+}
+
+// Decode side: what src/luma_quantizer.cpp:447-448 make of a table value, y = (255 PQenc(lut[i]) - 16) / 219.
+void ycbcr_ytab_host(const float *lut, size_t n, float Lmax, float *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float y = pq_encode_host(Lmax, lut[i]);
+        out[i] = (255.0f * y - 16.0f) / 219.0f;
+    }
+}
+
+}  // namespace lh

@@ -294,7 +294,13 @@ LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, f
 }
 
 // RGB -> Y'CbCr (BT.2020, PQ): src/luma_quantizer.cpp:317-354
-template <bool REGULAR>
+// YCODE: channel 0 leaves as t = 219 y + 16 (the numerator of src/luma_quantizer.cpp:337, y = the luma) instead of
+// PQdec(t / 255): the encode kernel then takes the luminance CODE straight from threshold records built for the composite
+// function t -> search(PQdec(t / 255)) (host_lut.cpp ycbcr_luma_code_host, evaluated with the host libm; lut_index.hpp
+// build_thresh_index_fn) -- two powf, a division and the table search collapse into one 4-byte LDS gather.  y is >= +0 or
+// NaN (a sum of non-negative products), so t is >= 16 or NaN, which is what the NONNEG form of the record search needs;
+// beyond t ~ 508 and for NaN the reference's arithmetic ends in code maxVal, and so does the records' top bucket.
+template <bool REGULAR, bool YCODE = false>
 LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2, SlowAcc &slow)
 {
     float R, G, B;
@@ -311,11 +317,17 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
     if constexpr (REGULAR) {
         // R, G, B in [7e-7, 2] once the three input tests passed (pq_encode_r), so y is too: 219y+16 in [16, 454];
         // 224t+128 (never -0) is finite; |B-y|, |R-y| <= ~2.1, zero or >= ~1e-13
-        c0 = pq_decode_r<true>(div_255_pos(219.0f * y + 16.0f), k, slow);
+        if constexpr (YCODE)
+            c0 = 219.0f * y + 16.0f;
+        else
+            c0 = pq_decode_r<true>(div_255_pos(219.0f * y + 16.0f), k, slow);
         c1 = div_255_pos(224.0f * div_nr_r(B - y, 1.8814f, k.r18814) + 128.0f);
         c2 = div_255_pos(224.0f * div_nr_r(R - y, 1.4746f, k.r14746) + 128.0f);
     } else {
-        c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
+        if constexpr (YCODE)
+            c0 = 219.0f * y + 16.0f;
+        else
+            c0 = pq_decode(div_ieee(219.0f * y + 16.0f, 255.0f), k);
         c1 = div_ieee(224.0f * div_ieee(B - y, 1.8814f) + 128.0f, 255.0f);
         c2 = div_ieee(224.0f * div_ieee(R - y, 1.4746f) + 128.0f, 255.0f);
     }
@@ -324,7 +336,7 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
 // N pixels at once: straight-line evaluation first; if any of them had a NaN / inf / denormal / out-of-range power
 // argument (rare), all N are redone with the complete powf.  Both produce identical bits wherever the straight-line
 // form applies.  One flag and one branch per thread and unit, not per pixel.
-template <int N>
+template <int N, bool YCODE = false>
 LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], const XformConst &k, float (&c0)[N],
                         float (&c1)[N], float (&c2)[N])
 {
@@ -332,10 +344,10 @@ LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&
     slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
 #pragma unroll
     for (int i = 0; i < N; i++)
-        ycbcr_fwd<true>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
+        ycbcr_fwd<true, YCODE>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
     if (__builtin_expect(slow_any(slow, k), 0)) {
         for (int i = 0; i < N; i++)  // not unrolled: cold code
-            ycbcr_fwd<false>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
+            ycbcr_fwd<false, YCODE>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
     }
 }
 
@@ -362,19 +374,28 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 }
 
 // Y'CbCr -> RGB: src/luma_quantizer.cpp:436-473
-template <bool REGULAR>
+// YT: c0 is already y = (255 PQenc(table value) - 16) / 219, read from the per-stream table the host built with its libm
+// (host_lut.cpp ycbcr_ytab_host; QuantDev::ytab): the first of the four PQ evaluations of a pixel depends on the luminance
+// CODE alone, so it is done once per table entry and stream instead of once per pixel.
+template <bool REGULAR, bool YT = false>
 LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, SlowAcc &slow)
 {
     float y, blue, red, green;
     if constexpr (REGULAR) {
         // c0 is a table value in {0} u [1e-6, Lmax]; c1, c2 in [1e-10, ~260]: 255y-16 is finite and never -0,
         // the other numerators are zero or of magnitude >= ~1e-8 and <= ~1e5
-        y = div_219_fin(255.0f * pq_encode_r<true>(c0, k, slow) - 16.0f);
+        if constexpr (YT)
+            y = c0;
+        else
+            y = div_219_fin(255.0f * pq_encode_r<true>(c0, k, slow) - 16.0f);
         blue = y + div_nr_r(1.8814f * (255.0f * c1 - 128.0f), 224.0f, k.r224);
         red = y + div_nr_r(1.4746f * (255.0f * c2 - 128.0f), 224.0f, k.r224);
         green = div_nr_r((y - 0.2627f * red) - 0.0593f * blue, 0.6780f, k.r0678);
     } else {
-        y = div_ieee(255.0f * pq_encode(c0, k) - 16.0f, 219.0f);
+        if constexpr (YT)
+            y = c0;
+        else
+            y = div_ieee(255.0f * pq_encode(c0, k) - 16.0f, 219.0f);
         blue = y + div_ieee(1.8814f * (255.0f * c1 - 128.0f), 224.0f);
         red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
         green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
@@ -400,7 +421,7 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
     }
 }
 
-template <int N>
+template <int N, bool YT = false>
 LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const XformConst &k, float (&r)[N],
                         float (&g)[N], float (&b)[N])
 {
@@ -409,12 +430,16 @@ LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float 
 #pragma unroll
     for (int i = 0; i < N; i++) {
         // out-of-range colour codes (c1, c2 > 1) or a non-finite table value leave the licensed ranges: slow path
-        slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f && c0[i] <= 3.0e38f);
-        ycbcr_inv<true>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+        // (YT: the y table exists only for tables whose entries are all finite and non-negative, lumahip_core.hip)
+        if constexpr (YT)
+            slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f);
+        else
+            slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f && c0[i] <= 3.0e38f);
+        ycbcr_inv<true, YT>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
     }
     if (__builtin_expect(slow_any(slow, k), 0)) {
         for (int i = 0; i < N; i++)  // not unrolled: cold code
-            ycbcr_inv<false>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+            ycbcr_inv<false, YT>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
     }
 }
 
@@ -531,7 +556,8 @@ LH_DEVS void xform_inv<CS_RGB>(float c0, float c1, float c2, const XformConst &k
 // ---------------------------------------------------------------------------------------------------
 struct QuantDev {
     const float *lut;        // global: maxVal+1 floats followed by `pad` NaNs
-    const uint32_t *rec;     // global: nbuckets threshold records (modes 3, 4; lut_index.hpp)
+    const uint32_t *rec;     // global: nbuckets threshold records (modes 3, 4, 5; lut_index.hpp)
+    const float *ytab;       // global, nullable: YCbCr decode, y = (255 PQenc(lut[i]) - 16) / 219 per table entry (host_lut.cpp)
     int lut_len;             // maxVal + 1
     int pad;
     int maxVal;
@@ -674,11 +700,14 @@ LH_DEV void quantize_thresh(const float (&v)[N], int (&code)[N], RecPtr rec, con
 }
 
 // MODE (lut_index.hpp LutMode): 0 literal bisection (table in LDS), 2 literal bisection (table in global memory),
-//       3 / 4 threshold records (LDS / global); `idx` = the records for 3 / 4, unused otherwise
+//       3 / 4 threshold records (LDS / global); `idx` = the records for 3 / 4, unused otherwise;
+//       5 = records (LDS) of the YCbCr composite t -> code (ycbcr_fwd<., YCODE>): v is t = 219 y + 16, >= 16 or NaN
 template <int MODE, int N, bool NONNEG = false, typename LutPtr, typename IdxPtr>
 LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, IdxPtr idx, const QuantDev &q)
 {
-    if constexpr (MODE == 3 || MODE == 4) {
+    if constexpr (MODE == 5) {
+        quantize_thresh<N, true>(v, code, idx, q);
+    } else if constexpr (MODE == 3 || MODE == 4) {
         quantize_thresh<N, NONNEG>(v, code, idx, q);
     } else {
 #pragma unroll

@@ -74,7 +74,7 @@ struct DecArgs {
 // [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B]
 // [u'v' table: maxC+1 floats (Lu'v' decode only), see luv_chroma_uv].
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
-enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16 };
+enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16, STAGE_YT = 32 };
 
 // fill the LDS copy of the powf tables (pow_glibc.hpp); the caller synchronises
 LH_DEV void stage_powf_tables(PowfTablesWide *t)
@@ -122,6 +122,14 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q)
         uint4 *sb = reinterpret_cast<uint4 *>(smem + off);
         for (int i = tid; i < b4; i += nt)
             sb[i] = gb[i];
+    }
+    if constexpr (WHAT & STAGE_YT) {
+        static_assert((WHAT & STAGE_LUT) && !(WHAT & STAGE_UV), "the y table of the YCbCr decode kernels sits behind the luminance table");
+        const int n4 = lds_lut_bytes(q) / 16;  // same length and padding as the luminance table
+        const float4 *g = reinterpret_cast<const float4 *>(q.ytab);
+        float4 *s = reinterpret_cast<float4 *>(smem + off + lds_lut_bytes(q));
+        for (int i = tid; i < n4; i += nt)
+            s[i] = g[i];
     }
     if constexpr (WHAT & STAGE_UV) {
         static_assert(WHAT & STAGE_LUT, "the u'v' table sits behind the luminance table");
@@ -263,7 +271,8 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 
 // ---- ENCODE ---------------------------------------------------------------------------------------
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
-// LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global).
+// LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global;
+// 5 = YCbCr only: records in LDS for the composite luma -> code function, channel 0 carries the luma y, luma_device.hpp ycbcr_fwd).
 //
 // Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued at the end of the current
 // unit's iteration, one full iteration before they are needed (without this the kernel sat at ~45 % SQ_WAIT_ANY,
@@ -346,7 +355,7 @@ LH_DEV void stats_flush(EncStats &st, float *stats, int tx)
 }
 
 // colour transform of one unit (row-major pixel order inside the unit: j = r*VW + i)
-template <int CS, int VW>
+template <int CS, int VW, bool YCODE = false>
 LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k, float (&c0)[2 * VW],
                           float (&c1)[2 * VW], float (&c2)[2 * VW], EncStats &st)
 {
@@ -369,7 +378,7 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
                 g8[r * VW + i] = u.in[1][r][i];
                 b8[r * VW + i] = u.in[2][r][i];
             }
-        ycbcr_fwd_n<2 * VW>(r8, g8, b8, k, c0, c1, c2);  // one "redo with the complete powf" decision per unit
+        ycbcr_fwd_n<2 * VW, YCODE>(r8, g8, b8, k, c0, c1, c2);  // one "redo with the complete powf" decision per unit
     } else {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -477,7 +486,8 @@ template <int CS, bool SUB, int VW, int LM>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | (LM == 3 ? STAGE_REC : 0) | (CS == CS_YCBCR ? STAGE_POWF : 0);
+    static_assert(LM != 5 || CS == CS_YCBCR, "the composite records belong to the YCbCr kernels");
+    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 5) ? STAGE_REC : 0) | (CS == CS_YCBCR ? STAGE_POWF : 0);
     stage_tables<WHAT>(smem, a.q);
 
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());        // LM == 0
@@ -512,9 +522,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         const int f = u.f, ux = u.ux, uy = u.uy;
         float c0[2 * VW], c1[2 * VW], c2[2 * VW];
         if (valid)
-            enc_transform<CS, VW>(u, a, k, c0, c1, c2, st);
+            enc_transform<CS, VW, LM == 5>(u, a, k, c0, c1, c2, st);
         if (valid) {
-            if constexpr (LM == 3)
+            if constexpr (LM == 3 || LM == 5)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
             else if constexpr (LM == 4)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, a.q.rec);
@@ -585,7 +595,7 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
-template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, typename LutPtr>
+template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, typename LutPtr>
 LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, const float *s_uv)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
@@ -596,7 +606,7 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
     for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int i = 0; i < VW; i++)
-            c0[r * VW + i] = dequantize_lut(u.y[r][i], lut, maxVal);
+            c0[r * VW + i] = dequantize_lut(u.y[r][i], YT ? LutPtr(s_uv) : lut, maxVal);   // YT: the y table (behind the table in LDS)
     if constexpr (SUB) {
         constexpr int NQ = VW / 2;
 #pragma unroll
@@ -640,7 +650,7 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
                 luv_apply(c0[r * VW + i], ch[SUB ? i / 2 : r * VW + i], out[0][r][i], out[1][r][i], out[2][r][i]);
     } else if constexpr (CS == CS_YCBCR) {
         float r8[2 * VW], g8[2 * VW], b8[2 * VW];
-        ycbcr_inv_n<2 * VW>(c0, c1, c2, k, r8, g8, b8);
+        ycbcr_inv_n<2 * VW, YT>(c0, c1, c2, k, r8, g8, b8);
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -713,13 +723,15 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
 
 // DISP: additionally (or only) emit the RGBA8 display image -- a separate instantiation so that the plain
 // decoder does not carry the epilogue's registers (it cost 8 % when it was a run-time branch)
-template <int CS, bool SUB, int VW, bool GL, bool DISP = false>
+// YT (YCbCr, table in LDS): additionally stage the per-stream y table and skip the first PQ evaluation of every pixel
+template <int CS, bool SUB, int VW, bool GL, bool DISP = false, bool YT = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(!YT || (CS == CS_YCBCR && !GL), "the y table belongs to the YCbCr kernels with the table in LDS");
     // GL: transfer-function table or chroma depth beyond 12 bits -- tables stay in global memory / are not built
     constexpr bool UVTAB = (CS == CS_LUV && !GL);
-    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0);
+    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0) | (YT ? STAGE_YT : 0);
     stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
     const float *s_uv = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_lut_bytes(a.q));
@@ -736,7 +748,7 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
             if constexpr (GL)
                 dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
             else
-                dec_process<CS, SUB, VW, DISP, UVTAB>(cur, a, k, s_lut, s_uv);
+                dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv);
         }
         // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
         // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)

@@ -67,7 +67,8 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_LDS_TABLE_MAX_KB", "lds_table_max_kb"},
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
-                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_COPY_SPIN", "copy_spin"}};
+                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
+                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
                 (void)lumahip_tune(c, k[1], atol(e));
@@ -84,6 +85,8 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_rec_y);
+    (void)hipFree(c->d_ytab);
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
@@ -245,6 +248,10 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->force_literal = v != 0;
         if (c->have_quant)
             return requantize(c);
+    } else if (k == "ycbcr_tables") {
+        c->use_ycbcr_tables = v != 0;
+        if (c->have_quant)
+            return requantize(c);
     } else if (k == "host_bands") {
         if (v < 1 || v > lumahip_ctx::MAX_BANDS)
             return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
@@ -299,6 +306,32 @@ std::shared_ptr<const ThreshIndex> cached_thresh_index(const std::vector<float> 
     g_index_cache.push_back(e);
     return e.ix;
 }
+struct YIndexCacheEntry {
+    std::vector<float> lut;
+    float Lmax;
+    std::shared_ptr<const ThreshIndex> ix;
+};
+std::vector<YIndexCacheEntry> g_yindex_cache;
+
+// records of the YCbCr composite  t -> search(PQdec(t / 255)), t = 219 y + 16  (host_lut.cpp ycbcr_luma_code_host), per (table, Lmax)
+std::shared_ptr<const ThreshIndex> cached_ycbcr_index(const std::vector<float> &lut, float Lmax)
+{
+    std::lock_guard<std::mutex> lk(g_index_mutex);
+    for (auto &e : g_yindex_cache)
+        if (e.lut.size() == lut.size() && memcmp(&e.Lmax, &Lmax, sizeof(float)) == 0 &&
+            memcmp(e.lut.data(), lut.data(), lut.size() * sizeof(float)) == 0)
+            return e.ix;
+    YIndexCacheEntry e;
+    e.lut = lut;
+    e.Lmax = Lmax;
+    const int maxVal = (int)lut.size() - 1;
+    e.ix = std::make_shared<const ThreshIndex>(build_thresh_index_fn(
+        [&](float t) { return ycbcr_luma_code_host(t, lut.data(), maxVal, Lmax); }, maxVal, 1 << 16, true));
+    if (g_yindex_cache.size() >= 8)
+        g_yindex_cache.erase(g_yindex_cache.begin());
+    g_yindex_cache.push_back(e);
+    return e.ix;
+}
 }  // namespace
 
 // device copy of the table + the decode-side decisions: everything a decoder needs
@@ -314,13 +347,35 @@ static int upload_table(lumahip_ctx *c)
     memcpy(padded.data(), c->h_lut.data(), n * sizeof(float));
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_rec_y);
+    (void)hipFree(c->d_ytab);
     c->d_lut = nullptr;
     c->d_rec = nullptr;
+    c->d_rec_y = nullptr;
+    c->d_ytab = nullptr;
+    c->tix_y.reset();
     HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
     QuantDev &q = c->q;
     q.lut = c->d_lut;
     q.rec = nullptr;
+    q.ytab = nullptr;
+    if (c->q.cs == CS_YCBCR && c->use_ycbcr_tables && c->lut_in_lds) {
+        // YCbCr decode: the first PQ evaluation of a pixel depends on its luminance code only -- one table per stream, built
+        // with the host libm (the function the reference calls).  Only for tables of finite non-negative values: the
+        // kernels' range analysis of what follows (luma_device.hpp ycbcr_inv) assumes them.
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++)
+            ok = c->h_lut[i] >= 0.0f && c->h_lut[i] <= 3.0e38f;
+        const size_t both = 2 * (((n + 4) * sizeof(float) + 15) & ~(size_t)15) + 64 + powf_b;
+        if (ok && both <= LUMAHIP_LDS_PER_WORKGROUP) {
+            std::vector<float> yt(lut_floats, 0.0f);
+            ycbcr_ytab_host(c->h_lut.data(), n, c->q.Lmax, yt.data());
+            HIPCHK(c, hipMalloc(&c->d_ytab, lut_floats * sizeof(float)));
+            HIPCHK(c, hipMemcpy(c->d_ytab, yt.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
+            q.ytab = c->d_ytab;
+        }
+    }
     q.lut_len = (int)n;
     q.pad = (int)(lut_floats - n);
     q.maxVal = (int)n - 1;                                   // (int)pow(2,bitdepth)-1, src/luma_quantizer.cpp:180
@@ -363,6 +418,24 @@ int lhost::ensure_search_index(lumahip_ctx *c)
             q.shift = ix.shift;
             q.kmin = ix.kmin;
             q.nbuckets = ix.nbuckets;
+            // YCbCr encode: the luminance code straight from the luma y (composite records; luma_device.hpp ycbcr_fwd<., YCODE>)
+            if (q.cs == CS_YCBCR && c->use_ycbcr_tables && q.mode == LUT_THRESH_LDS) {
+                c->tix_y = cached_ycbcr_index(c->h_lut, q.Lmax);
+                const ThreshIndex &iy = *c->tix_y;
+                if (iy.ok && iy.rec.size() * 4 <= c->lds_table_max && iy.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP) {
+                    std::vector<uint32_t> ry((iy.rec.size() + 3) & ~(size_t)3, 0u);
+                    memcpy(ry.data(), iy.rec.data(), iy.rec.size() * sizeof(uint32_t));
+                    (void)hipFree(c->d_rec_y);
+                    c->d_rec_y = nullptr;
+                    HIPCHK(c, hipMalloc(&c->d_rec_y, ry.size() * sizeof(uint32_t)));
+                    HIPCHK(c, hipMemcpy(c->d_rec_y, ry.data(), ry.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    c->q_y = q;
+                    c->q_y.rec = c->d_rec_y;
+                    c->q_y.shift = iy.shift;
+                    c->q_y.kmin = iy.kmin;
+                    c->q_y.nbuckets = iy.nbuckets;
+                }
+            }
         }
     }
     c->index_ready = true;
@@ -448,13 +521,45 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
 
 namespace lhost {
 
+// host-only views of the two per-stream YCbCr tables (no GPU, no context), for the CPU tests
+extern "C" int lumahip_ycbcr_luma_index_host(const float *lut, size_t n, float Lmax, int info[5], uint32_t *rec_out, size_t rec_cap)
+{
+    if (!lut || !info || n < 2 || n > 65536)
+        return LUMAHIP_ERR_ARG;
+    const int maxVal = (int)n - 1;
+    const ThreshIndex ix = build_thresh_index_fn([&](float t) { return ycbcr_luma_code_host(t, lut, maxVal, Lmax); }, maxVal, 1 << 16, true);
+    info[0] = ix.ok ? 1 : 0;
+    info[1] = ix.mant_bits;
+    info[2] = ix.shift;
+    info[3] = ix.kmin;
+    info[4] = ix.nbuckets;
+    if (rec_out && ix.ok) {
+        if (rec_cap < ix.rec.size())
+            return LUMAHIP_ERR_ARG;
+        memcpy(rec_out, ix.rec.data(), ix.rec.size() * sizeof(uint32_t));
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float Lmax, float *out)
+{
+    if (!lut || !out || n < 1)
+        return LUMAHIP_ERR_ARG;
+    ycbcr_ytab_host(lut, n, Lmax, out);
+    return LUMAHIP_OK;
+}
+
 // dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)
-size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
+bool ycbcr_composite_ready(const lumahip_ctx *c) { return c->q.cs == CS_YCBCR && c->d_rec_y != nullptr && c->index_ready; }
+
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode)
 {
     const QuantDev &q = c->q;
     size_t b = 0;
     const size_t lut_b = ((size_t)(q.lut_len + q.pad) * 4 + 15) & ~(size_t)15;
-    if (encode_side) {
+    if (encode_side && ycode) {
+        b += ((size_t)c->q_y.nbuckets * 4 + 15) & ~(size_t)15;
+    } else if (encode_side) {
         if (q.mode == LUT_LITERAL_LDS)
             b += lut_b;
         if (q.mode == LUT_THRESH_LDS)
@@ -463,6 +568,8 @@ size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff)
         b += lut_b;
         if (cs_eff == CS_LUV)
             b += (((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15;  // u'v' table of the Lu'v' decode kernels
+        if (cs_eff == CS_YCBCR && q.ytab)
+            b += lut_b;                                          // y table of the YCbCr decode kernels
     }
     if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTablesWide);

@@ -66,8 +66,12 @@ __global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
 typedef void (*dec_kernel_t)(const DecArgs);
 
 template <int CS, bool SUB>
-static dec_kernel_t pick_dec2(int vw, bool gl, bool disp)
+static dec_kernel_t pick_dec2(int vw, bool gl, bool disp, bool yt)
 {
+    if constexpr (CS == CS_YCBCR) {
+        if (yt && !gl && !disp)   // per-stream y table in LDS
+            return vw == 4 ? k_decode<CS, SUB, 4, false, false, true> : k_decode<CS, SUB, 2, false, false, true>;
+    }
     if (disp) {
         if (gl)
             return k_decode<CS, SUB, 2, true, true>;
@@ -78,14 +82,14 @@ static dec_kernel_t pick_dec2(int vw, bool gl, bool disp)
     return vw == 4 ? k_decode<CS, SUB, 4, false> : k_decode<CS, SUB, 2, false>;
 }
 
-static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp)
+static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp, bool yt)
 {
     switch (cs) {
-    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp) : pick_dec2<CS_LUV, false>(vw, gl, disp);
-    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp) : pick_dec2<CS_RGB, false>(vw, gl, disp);
-    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp) : pick_dec2<CS_YCBCR, false>(vw, gl, disp);
-    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp) : pick_dec2<CS_XYZ, false>(vw, gl, disp);
-    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp) : pick_dec2<CS_PACK, false>(vw, gl, disp);
+    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp, yt) : pick_dec2<CS_LUV, false>(vw, gl, disp, yt);
+    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp, yt) : pick_dec2<CS_RGB, false>(vw, gl, disp, yt);
+    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp, yt) : pick_dec2<CS_YCBCR, false>(vw, gl, disp, yt);
+    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp, yt) : pick_dec2<CS_XYZ, false>(vw, gl, disp, yt);
+    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp, yt) : pick_dec2<CS_PACK, false>(vw, gl, disp, yt);
     }
     return nullptr;
 }
@@ -118,7 +122,12 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
         return fail(c, LUMAHIP_ERR_ARG, "display buffer must be 4-byte aligned with stride >= 4*w");
     DecArgs a{};
     a.q = c->q;
-    const size_t lds = lds_bytes(c, false, cs_eff);
+    const bool yt = cs_eff == CS_YCBCR && c->q.ytab && !gl && dp.rgba == nullptr;
+    if (!yt)
+        a.q.ytab = nullptr;
+    size_t lds = lds_bytes(c, false, cs_eff);
+    if (cs_eff == CS_YCBCR && c->q.ytab && !yt)
+        lds -= ((size_t)(c->q.lut_len + c->q.pad) * 4 + 15) & ~(size_t)15;   // (display variant: no y table)
     const int threads = block_threads_for(c, lds);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
@@ -146,7 +155,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
             a.aligned = 0;
     }
     a.q.cs = cs_eff;
-    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr);
+    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr, yt);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr, cs_eff == CS_YCBCR);

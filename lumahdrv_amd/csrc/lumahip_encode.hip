@@ -45,6 +45,10 @@ typedef void (*enc_kernel_t)(const EncArgs);
 template <int CS, bool SUB>
 static enc_kernel_t pick_enc2(int vw, int mode)
 {
+    if constexpr (CS == CS_YCBCR) {
+        if (mode == 5)   // composite luma -> code records (vw == 4 or 2 as for the records)
+            return vw == 4 ? k_encode<CS, SUB, 4, 5> : k_encode<CS, SUB, 2, 5>;
+    }
     if (mode == LUT_THRESH_LDS)
         return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
     if (mode == LUT_THRESH_GLOBAL)
@@ -119,9 +123,11 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     int vw = (fast_search && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb[0], 8) || !is_aligned(rgb[1], 8) || !is_aligned(rgb[2], 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
+    // YCbCr without per-frame statistics (they need the luminance itself): the luminance code comes straight from the luma
+    const bool ycode = cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
     EncArgs a{};
-    a.q = c->q;
-    const size_t lds = lds_bytes(c, true, cs_eff);
+    a.q = ycode ? c->q_y : c->q;
+    const size_t lds = lds_bytes(c, true, cs_eff, ycode);
     const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
     const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
@@ -144,7 +150,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
             a.aligned = 0;
     }
     a.q.cs = cs_eff;
-    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, mode);
+    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, ycode ? 5 : mode);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
@@ -270,3 +276,60 @@ extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, 
     return LUMAHIP_OK;
 }
 
+
+// ---- test probe: the luminance code of a YCbCr pixel as a function of t = 219 y + 16 (y = its luma), over consecutive fp32 bit patterns ----
+// direct = 0: through the composite records exactly as k_encode<CS_YCBCR, ., ., 5> reads them (quantize_thresh<4, NONNEG>);
+// direct = 1: the reference's arithmetic on the device -- PQdec((219 y + 16) / 255) with the complete powf and IEEE division,
+// then the literal table search.  tests/test_gpu_exhaustive.py compares the two for every t >= +0 and every NaN.
+namespace lh {
+__global__ __launch_bounds__(256) void k_ycbcr_luma_probe(const QuantDev q, const QuantDev qy, float Lmax, uint16_t *out, uint32_t first_bits,
+                                                          size_t n4, int direct)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PowfTablesWide *pw = reinterpret_cast<PowfTablesWide *>(smem);
+    stage_powf_tables(pw);
+    uint32_t *s_rec = reinterpret_cast<uint32_t *>(smem + sizeof(PowfTablesWide));
+    for (int i = threadIdx.x; i < qy.nbuckets; i += blockDim.x)
+        s_rec[i] = qy.rec[i];
+    __syncthreads();
+    const XformConst k = make_xform_const<CS_YCBCR>(1.0f, Lmax, pw);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float v[4];
+        int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = __uint_as_float(first_bits + (uint32_t)(4 * i + j));
+        if (direct) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                c[j] = quantize_lut_literal(pq_decode(div_ieee(v[j], 255.0f), k), q.lut, q.maxVal);
+        } else {
+            quantize_lut<5, 4>(v, c, q.lut, s_rec, qy);
+        }
+        store_samples<4>(reinterpret_cast<unsigned char *>(out + 4 * i), c, 2, 1);
+    }
+}
+}  // namespace lh
+
+extern "C" int lumahip_ycbcr_luma_probe_device(lumahip_ctx *c, uint16_t *out_dev, uint32_t first_bits, size_t n, int direct)
+{
+    if (!c || !out_dev || n == 0 || (n % 4) != 0 || !is_aligned(out_dev, 8))
+        return fail(c, LUMAHIP_ERR_ARG, "bad argument (n must be a multiple of 4, out 8-byte aligned)");
+    if (!c->have_quant || c->q.cs != CS_YCBCR)
+        return fail(c, LUMAHIP_ERR_STATE, "the probe needs a YCbCr quantizer");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_search_index(c))
+        return rc;
+    if (!ycbcr_composite_ready(c))
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "no composite luma -> code records for this table");
+    const size_t lds = sizeof(PowfTablesWide) + (((size_t)c->q_y.nbuckets * 4 + 15) & ~(size_t)15);
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_ycbcr_luma_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long grid = (long)((n / 4 + 255) / 256);
+    if (grid > (long)c->num_cu * 8)
+        grid = (long)c->num_cu * 8;
+    hipLaunchKernelGGL(k_ycbcr_luma_probe, dim3((unsigned)grid), dim3(256), lds, c->stream, c->q, c->q_y, c->q.Lmax, out_dev, first_bits,
+                       n / 4, direct);
+    HIPCHK(c, hipGetLastError());
+    return LUMAHIP_OK;
+}

@@ -22,6 +22,7 @@
 
 #include "../../include/lumahip.h"
 #include "luma_kernels.hpp"
+#include "host_lut.hpp"
 #include "lut_index.hpp"
 
 // Largest search table (encode: threshold records, decode: the luminance table) a workgroup stages in LDS; beyond it
@@ -48,6 +49,12 @@ struct lumahip_ctx {
     lh::QuantDev q{};
     std::shared_ptr<const lh::ThreshIndex> tix;  // encode-side search index, built on first use (ensure_search_index)
     bool index_ready = false;
+    // YCbCr only: records of the composite luma -> code function (encode), the per-stream y table (decode); host_lut.cpp
+    std::shared_ptr<const lh::ThreshIndex> tix_y;
+    uint32_t *d_rec_y = nullptr;
+    lh::QuantDev q_y{};           // q with the composite records in place of the luminance records
+    float *d_ytab = nullptr;
+    bool use_ycbcr_tables = true; // lumahip_tune("ycbcr_tables", 0): per-pixel PQ evaluation as in round 2 (A/B, tests)
     bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
     std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer
     float *d_lut = nullptr;
@@ -160,7 +167,8 @@ struct DisplayParams {
 
 // ---- lumahip_core.hip
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
-size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff);
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false);   // ycode: the composite-record encode kernels
+bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
 int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 
 namespace lh {
 
@@ -46,22 +47,29 @@ int thresh_lookup_host(const ThreshIndex &ix, float v)
 
 ThreshIndex build_thresh_index(const float *lut, int n, int max_buckets)
 {
-    ThreshIndex ix;
     const int maxVal = n - 1;
     if (n < 2 || n > 65536)
-        return ix;
+        return ThreshIndex();
     for (int i = 0; i < n; i++) {
         if (lut[i] != lut[i] || std::isinf(lut[i]))
-            return ix;
+            return ThreshIndex();
         if (i && lut[i] < lut[i - 1])
-            return ix;
+            return ThreshIndex();
     }
-    auto f = [&](uint32_t bits) { return quantize_literal_host(from_bits((int64_t)bits), lut, maxVal); };
+    return build_thresh_index_fn([&](float v) { return quantize_literal_host(v, lut, maxVal); }, maxVal, max_buckets, false);
+}
+
+ThreshIndex build_thresh_index_fn(const std::function<int(float)> &code, int maxVal, int max_buckets, bool nonneg_only)
+{
+    ThreshIndex ix;
+    if (maxVal < 1 || maxVal > 65535)
+        return ix;
+    auto f = [&](uint32_t bits) { return code(from_bits((int64_t)bits)); };
     const uint32_t PINF = 0x7f800000u;
     const int c0 = f(0u);
     // everything at or below +0 must share one code (then every threshold is a positive float and bit patterns
-    // of the non-negative half sort like the values)
-    if (quantize_literal_host(-__builtin_inff(), lut, maxVal) != c0 || f(PINF) != maxVal)
+    // of the non-negative half sort like the values); a caller that never presents negative values says so
+    if ((!nonneg_only && code(-__builtin_inff()) != c0) || f(PINF) != maxVal)
         return ix;
     std::vector<uint32_t> T;  // T[j] = smallest bit pattern whose code is >= c0 + 1 + j
     T.reserve((size_t)(maxVal - c0));
@@ -134,8 +142,17 @@ ThreshIndex build_thresh_index(const float *lut, int n, int max_buckets)
                 ix.ok = same((uint32_t)b);
         }
         ix.ok = ix.ok && same(0u) && same(PINF) && same(0x7fc00000u) &&
-                thresh_lookup_host(ix, -0.0f) == c0 && thresh_lookup_host(ix, -1.0f) == c0 &&
-                thresh_lookup_host(ix, -__builtin_inff()) == c0;
+                (nonneg_only || (thresh_lookup_host(ix, -0.0f) == c0 && thresh_lookup_host(ix, -1.0f) == c0 &&
+                                 thresh_lookup_host(ix, -__builtin_inff()) == c0));
+        // a step function that is not monotone between its thresholds cannot be told from one that is by the checks above.
+        // The table search is monotone by proof (lut_index.hpp); a caller-supplied function gets a strided sweep of every
+        // bucket (32 floats per bucket) against the literal function
+        for (int64_t k = std::max<int64_t>(kfirst - 1, 0); nonneg_only && k <= klast + 1 && ix.ok; k++) {
+            const int64_t a = k << shift, step = std::max<int64_t>(1, ((int64_t)1 << shift) / 32);
+            for (int64_t b2 = a; b2 < a + ((int64_t)1 << shift) && ix.ok; b2 += step)
+                if (b2 <= (int64_t)PINF)
+                    ix.ok = same((uint32_t)b2);
+        }
         if (!ix.ok)
             ix.rec.clear();
         return ix;

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace lh {
@@ -56,5 +57,9 @@ int quantize_literal_host(float v, const float *lut, int maxVal);
 // device-equivalent evaluation of a record table (v must not be a sign-set NaN)
 int thresh_lookup_host(const ThreshIndex &ix, float v);
 ThreshIndex build_thresh_index(const float *lut, int n, int max_buckets);
+// The same records for ANY non-decreasing step function code(v) on the non-negative floats with code(+inf) == maxVal
+// (nonneg_only: the kernels never present a negative value, so code() need not be constant below +0).  Used for the
+// composite "Y' -> luminance code" function of the YCbCr encode kernels (luma_device.hpp, ycbcr_luma_code).
+ThreshIndex build_thresh_index_fn(const std::function<int(float)> &code, int maxVal, int max_buckets, bool nonneg_only);
 
 }  // namespace lh

@@ -280,3 +280,54 @@ def test_lumaenc_batch_mode_writes_the_same_stream(tmp_path):
                        timeout=300)
     assert r.returncode == 0 and "3 shard(s)" in r.stderr and "7 frames encoded" in r.stderr, r.stderr[-2000:]
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("profile", [2, 3])
+def test_ycbcr_stream_tables_do_not_change_a_bit(oracle_mod, profile):
+    """YCbCr with the per-stream tables (composite luminance-code records on encode, y table on decode: the default) against the
+    same kernels evaluating every PQ function per pixel (lumahip_tune "ycbcr_tables" 0) and against the oracle; with per-frame
+    statistics requested the encode side takes the per-pixel path by itself and must still agree."""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    cfg = CFGS["pq10_ycbcr"]
+    sc = cfg[6]
+    w, h, B = 1280, 720, 3
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(B * n3, dtype=torch.float32, device=dev)
+    res = {}
+    for tables in (1, 0):
+        c = L.Context(0)
+        c.tune("ycbcr_tables", tables)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_quantizer(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+        c.synth_frames_device(src.data_ptr(), n3, B, w, h, 21, 0)
+        # a few extreme pixels: black, huge, NaN, inf
+        s3 = src.view(B, 3, h, w)
+        s3[0, :, 0, 0:4] = 0.0
+        s3[0, :, 0, 4:8] = 3.0e38
+        s3[0, 0, 0, 8] = float("nan")
+        s3[0, 1, 0, 12] = float("inf")
+        planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        stats = torch.zeros(3 * B, dtype=torch.float32, device=dev)
+        c.encode_frames_device(src.data_ptr(), n3, B, w, h, sc, profile, [p.data_ptr() for p in planes], st, psz)
+        planes_s = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        c.encode_frames_device(src.data_ptr(), n3, B, w, h, sc, profile, [p.data_ptr() for p in planes_s], st, psz, stats.data_ptr())
+        out = torch.empty(B * n3, dtype=torch.float32, device=dev)
+        c.decode_frames_device([p.data_ptr() for p in planes], st, psz, B, w, h, profile, sc, out.data_ptr(), n3)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(planes, planes_s))
+        res[tables] = ([p.cpu().numpy() for p in planes], out.cpu().numpy(), src.cpu().numpy().copy())
+        c.set_stream(None)
+        c.close()
+    assert all(np.array_equal(a, b) for a, b in zip(res[1][0], res[0][0]))
+    assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    orc = o.Oracle(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5])
+    f0 = res[1][2][:n3].reshape(3, h, w).copy()
+    e, _, _ = orc.encode(f0, sc, profile)
+    got = [res[1][0][p][:psz[p]].reshape(hs[p], st[p]) for p in range(3)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, e))
+    assert np.array_equal(res[1][1][:n3].reshape(3, h, w).view(np.uint32), orc.decode(e, st, w, h, sc, profile).view(np.uint32))

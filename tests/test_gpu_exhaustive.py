@@ -296,3 +296,39 @@ def test_ycbcr_decode_every_code_triple_of_the_hdr10_recipe(oracle_mod):
         exp = orc.decode(planes, st, w, h, 20.0, 3, threads=nthreads)
         same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
         assert bool(same.all()), (k, np.argwhere(~same)[:4].tolist())
+
+
+@pytest.mark.parametrize("ptf,bits,mx", [(1, 10, 1000.0), (1, 11, 1e4), (1, 12, 1e4), (2, 12, 1e4)])
+def test_ycbcr_composite_records_equal_the_reference_arithmetic_for_every_float(ptf, bits, mx):
+    """YCbCr encode: the luminance code is read from threshold records of the composite function
+    t = 219 y + 16 -> search(PQdec(t / 255)) instead of two powf, a division and the table search per pixel.  Every float
+    t in [16, +inf] and every NaN of either sign through the kernels' own lookup (quantize_thresh<4, NONNEG> on the LDS copy)
+    against the reference's arithmetic evaluated on the device with the complete powf, IEEE division and the literal bisection
+    -- whose equality with the host libm / the oracle the other tests of this file and tests/test_gpu_parity.py establish."""
+    import torch
+    import lumahdrv_amd as L
+    dev = torch.device("cuda:0")
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_quantizer(ptf, bits, L.CS_YCBCR, 10, mx, 0.005, L.build_lut(ptf, bits, mx, 0.005))
+    n = 1 << 26
+    a = torch.empty(n, dtype=torch.int16, device=dev)
+    b = torch.empty(n, dtype=torch.int16, device=dev)
+    bad = 0
+    ranges = [(0x41800000, 0x7f800000 + 1 - 0x41800000), (0x7f800000, 1 << 23), (0xff800000, 1 << 23)]   # [16, inf], NaNs, sign-set NaNs (+ -inf)
+    for first, count in ranges:
+        done = 0
+        while done < count:
+            m = min(n, (count - done + 3) // 4 * 4)
+            fb = (first + done) & 0xFFFFFFFF
+            if fb == 0xff800000:
+                fb += 4                      # skip -inf itself: t = -inf cannot occur (t >= 16 or NaN)
+                m -= 4
+            ctx.ycbcr_luma_probe_device(a.data_ptr(), fb, m, direct=False)
+            ctx.ycbcr_luma_probe_device(b.data_ptr(), fb, m, direct=True)
+            bad += int((a[:m] != b[:m]).sum().item())
+            done += n
+    assert bad == 0
+    assert int(b[:4].max().item()) & 0xFFFF == (1 << bits) - 1        # the last block probed were NaNs: code maxVal
+    ctx.set_stream(None)
+    ctx.close()

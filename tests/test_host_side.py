@@ -318,3 +318,42 @@ def test_threshold_records_on_random_monotone_tables(L, oracle_mod):
         exp = (planes[0].view("<u2")[:, :w] if bits > 8 else planes[0][:, :w]).reshape(-1).astype(np.int64)
         assert np.array_equal(got & (0xFFFF if bits > 8 else 0xFF), exp), (trial, bits, kind)
     assert accepted >= 40 and accepted + refused == 60
+
+
+def test_ycbcr_stream_tables_equal_the_reference_arithmetic(L, oracle_mod):
+    """The two per-stream tables of the YCbCr kernels, built on the host with libm (host_lut.cpp): (1) the composite
+    "t = 219 y + 16 -> luminance code" threshold records against the oracle's PQdec(t / 255) + literal search
+    (src/luma_quantizer.cpp:337, 496-500, 222-235) around every threshold and on a dense sample; (2) the y table against
+    (255 PQenc(lut[i]) - 16) / 219 (src/luma_quantizer.cpp:447-448).  (The GPU suite sweeps every float >= 16 through the kernels' own
+    lookup.)"""
+    import ctypes as C
+    from lumahdrv_amd import capi
+    o = oracle_mod
+    lo = o.lib()
+    lo.lo_transform_pq.restype = C.c_float
+    lo.lo_transform_pq.argtypes = [C.c_float, C.c_float, C.c_int]
+    rng = np.random.default_rng(5)
+    for ptf, bits, mx in ((L.PTF_PQ, 10, 1000.0), (L.PTF_PQ, 11, 1e4), (L.PTF_LOG, 12, 1e4), (L.PTF_PQ, 8, 1e4)):
+        lut = L.build_lut(ptf, bits, mx, 0.005)
+        ix = capi.ycbcr_luma_index(lut, mx)
+        assert ix["ok"] and ix["nbuckets"] * 4 <= (64 << 10)
+        orc = o.Oracle(ptf, bits, o.CS_YCBCR, 10, mx, 0.005)
+
+        def want(t):
+            return np.array([int(orc.quantize(lo.lo_transform_pq(mx, float(x) / np.float32(255.0), 0), 0)) for x in (t / np.float32(255.0))])
+
+        # every bucket edge and both neighbours, a dense sample of [16, 600], the specials
+        k = np.arange(ix["kmin"], ix["kmin"] + ix["nbuckets"], dtype=np.int64)
+        edges = np.concatenate([(k << ix["shift"]), (k << ix["shift"]) - 1, ((k + 1) << ix["shift"]) - 1])
+        edges = edges[(edges >= 0x41800000) & (edges <= 0x7f800000)].astype(np.uint32).view(np.float32)
+        t = np.concatenate([edges[::7], rng.uniform(16, 600, 30000).astype(np.float32),
+                            np.array([16.0, 255.0, 507.9, 508.5, 1e30, np.inf], dtype=np.float32)])
+        v = t / np.float32(255.0)
+        exp = np.array([int(orc.quantize(lo.lo_transform_pq(mx, float(x), 0), 0)) for x in v])
+        assert np.array_equal(capi.thresh_lookup(ix, t), exp), (ptf, bits)
+        yt = capi.ycbcr_ytab(lut, mx)
+        e = np.array([(np.float32(255) * np.float32(lo.lo_transform_pq(mx, float(x), 1)) - np.float32(16)) / np.float32(219) for x in lut],
+                     dtype=np.float32)
+        assert np.array_equal(yt.view(np.uint32), e.view(np.uint32)), (ptf, bits)
+    # a table the composite cannot be built for (LINEAR-12: too many records) simply has none
+    assert not capi.ycbcr_luma_index(L.build_lut(L.PTF_LINEAR, 12, 1e4, 0.005), 1e4)["ok"]
