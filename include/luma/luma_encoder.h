@@ -36,6 +36,16 @@ class LumaEncoderBase {
 public:
     LumaEncoderBase() : m_initialized(false) {}
     virtual ~LumaEncoderBase() {}
+    // The reference's base class opens ITS container with a luminance range here (luma_encoder.h:83-91 there:
+    // m_writer.openWrite(outputFile, w, h, ma, mi)) and nothing else -- no parameters, no quantizer, m_initialized stays false;
+    // LumaEncoder's own four-argument initialize() hides it, as it does in the reference.  Same here: the derived class
+    // forwards the range to its sink and opens it.
+    virtual bool initialize(const char *outputFile, const unsigned int w, const unsigned int h, const float ma, const float mi,
+                            bool verbose = 0)
+    {
+        (void)outputFile, (void)w, (void)h, (void)ma, (void)mi, (void)verbose;
+        return true;
+    }
     virtual bool run() = 0;
     virtual void setChannels(LumaFrame *frame) = 0;
     virtual bool encode(LumaFrame *frame) = 0;
@@ -54,16 +64,10 @@ public:
 
     // throws LumaException("Invalid frame size") for zero or odd dimensions, like the reference
     bool initialize(const char *outputFile, const unsigned int w, const unsigned int h, bool verbose = 0);
-    // LumaEncoderBase::initialize(outputFile, w, h, ma, mi, verbose) of the reference (luma_encoder.h:88-96 there) opens
-    // the container with a luminance range; here the range goes where the container would record it: the parameters
-    // behind attachment 436 and the quantizer
+    // LumaEncoderBase::initialize(outputFile, w, h, ma, mi, verbose): opens the sink with the container-level luminance range
+    // only (see the base class); reachable through a LumaEncoderBase reference, hidden here by the overload above
     bool initialize(const char *outputFile, const unsigned int w, const unsigned int h, const float ma, const float mi,
-                    bool verbose = 0)
-    {
-        m_params.maxLum = ma;
-        m_params.minLum = mi;
-        return initialize(outputFile, w, h, verbose);
-    }
+                    bool verbose) override;
     bool run();
     // quantize + pack an ALREADY colour-transformed frame (what the reference's setChannels expects)
     void setChannels(LumaFrame *frame);

@@ -55,6 +55,13 @@ struct LumaAttachment {
 class LumaPlaneSink {
 public:
     virtual ~LumaPlaneSink() {}
+    // container-level luminance range (the reference's MkvInterface::openWrite(file, w, h, ma, mi) records it as HDR10
+    // mastering metadata, src/mkv_interface.cpp:155-180 there); called before open(); sinks without such metadata ignore it
+    virtual void setLuminanceRange(float maxLum, float minLum)
+    {
+        (void)maxLum;
+        (void)minLum;
+    }
     virtual void open(const char *file, unsigned int w, unsigned int h, int profile, float fps) = 0;
     virtual void addAttachment(unsigned int id, const void *data, size_t size, const char *description) = 0;
     virtual void writeAttachments() = 0;

@@ -230,8 +230,10 @@ int lumahip_transform_color_space_device(lumahip_ctx *ctx, float *frames_dev, si
  * of the host entry points and the per-frame `sum` statistic of lumahip_encode_frames_device come from the encode kernel
  * instead: an accurate sum, whereas the reference's drops / rounds small addends once its running sum is large (-0.2 % at
  * 1080p, several % at 4K on wide-range content).  The host entry points call this function themselves when their value
- * lies in [0.25, 4] -- the only range in which the two sums can fall on different sides of the threshold -- so the
- * `<= 1` decision they support is always the reference's. */
+ * lies in [0.25, 4] -- the only range in which the two sums can fall on different sides of the threshold for up to 2^25
+ * non-negative values -- and always for larger frames or when channel 0 holds negative values, so the `<= 1` decision they
+ * support is always the reference's.  Outside those cases mean_lum is the accurate statistic: correct to ~1e-6, but summed
+ * with float atomics, i.e. not reproducible in its last bits from run to run. */
 int lumahip_mean_luminance_reference_device(lumahip_ctx *ctx, const float *rgb_dev, unsigned w, unsigned h, float sc,
                                             float *mean_host);
 

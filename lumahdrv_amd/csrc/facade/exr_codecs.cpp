@@ -170,7 +170,11 @@ void huf_decode(const unsigned char *in, size_t nIn, std::vector<uint16_t> &out,
             l = (int)(e & 63);
             sym = e >> 6;
         } else {
-            const int maxl = left < 56 ? (int)left : 56;  // (longer codes cannot arise from a chunk's symbol counts)
+            // The format allows code lengths up to 58 bits; this reader holds at most 56 bits (a 64-bit accumulator refilled by
+            // whole bytes).  A Huffman code of length L needs a symbol count ratio of at least Fibonacci(L) between the most
+            // and the least frequent symbol, i.e. >= 1.4e11 samples in one chunk for L = 57 -- a chunk is at most 32 scan
+            // lines; OpenEXR itself never emits such codes.  Longer codes are reported as invalid data, not mis-decoded.
+            const int maxl = left < 56 ? (int)left : 56;
             for (l = FAST_BITS + 1; l <= maxl; l++) {
                 if (!br.fill(l))
                     throw LumaException("EXR/PIZ: truncated Huffman data");

@@ -39,6 +39,18 @@ bool LumaEncoder::initialize(const char *outputFile, const unsigned int w, const
     return true;
 }
 
+bool LumaEncoder::initialize(const char *outputFile, const unsigned int w, const unsigned int h, const float ma, const float mi,
+                             bool verbose)
+{
+    // what the reference's base class does: the container is opened with the range, nothing else changes
+    if (!m_sink)
+        m_sink = &m_rawWriter;
+    m_sink->setLuminanceRange(ma, mi);
+    m_sink->open(outputFile, w, h, (int)m_params.profile, m_params.fps);
+    (void)verbose;
+    return true;
+}
+
 void LumaEncoder::warnMean(float avg)
 {
     m_lastMean = avg;

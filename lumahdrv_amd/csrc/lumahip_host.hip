@@ -350,10 +350,17 @@ static void plane_layout(PlaneLayout &L, unsigned w, unsigned h, int profile, co
 // The reference warns when its (sequentially summed) mean luminance is <= 1.  That fp32 sum is far from the true sum on
 // large frames: once the running sum S is large, addends below ulp(S)/2 vanish and the rest are rounded to multiples of
 // ulp(S) (measured: -0.2 % at 1080p, several % at 4K on wide-range content), whereas the kernels' statistic (per-wave
-// partial sums) is accurate to ~1e-6.  Around the threshold S stays below N * 4, i.e. ulp(S)/2 <= 2 up to 8K frames, so
-// the two can only disagree about `<= 1` when the accurate mean lies in [0.25, 4]: inside that band the host entry points
-// replace the statistic by the reference's exact value (k_seq_sum), outside it the decision is the same either way.
-static bool mean_near_threshold(float m) { return m >= 0.25f && m <= 4.0f; }
+// partial sums) is accurate to ~1e-6.  For N <= 2^25 non-negative values (up to 8K frames) S stays below N * 4 around the
+// threshold, i.e. ulp(S)/2 <= 2, so the two can only disagree about `<= 1` when the accurate mean lies in [0.25, 4]: inside
+// that band the host entry points replace the statistic by the reference's exact value (k_seq_sum), outside it the decision
+// is the same either way.  The argument needs both premises, so frames beyond 2^25 pixels and frames whose channel 0 has
+// negative values (possible for CS_RGB and the pack-only entry points: cancellation, no bound) always take the exact sum.
+static bool mean_needs_reference_sum(float mean, float minimum, unsigned w, unsigned h)
+{
+    if ((size_t)w * h > ((size_t)1 << 25) || !(minimum >= 0.0f))
+        return true;
+    return mean >= 0.25f && mean <= 4.0f;
+}
 
 static int pipe_streams(lumahip_ctx *c);
 
@@ -497,7 +504,7 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mean_lum) {
         *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
-        if (mean_near_threshold(*mean_lum))  // d_frame holds the caller's frame, or already its transformed version
+        if (mean_needs_reference_sum(*mean_lum, st[1], w, h))  // d_frame holds the caller's frame, or already its transformed version
             return transformed_out ? seq_mean(c, c->d_frame, w, h, mean_lum)
                                    : mean_luminance_reference_impl(c, c->d_frame, w, h, sc, cs_eff, mean_lum);
     }
@@ -726,7 +733,7 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     if (rc == LUMAHIP_OK && mean_lum)
         for (unsigned i = 0; i < nframes && rc == LUMAHIP_OK; i++) {
             mean_lum[i] = c->h_stats[3 * (size_t)i] / (float)((int)w * (int)h);
-            if (mean_near_threshold(mean_lum[i])) {  // rare: redo this frame's sum in the reference's order
+            if (mean_needs_reference_sum(mean_lum[i], c->h_stats[3 * (size_t)i + 1], w, h)) {  // rare: redo this frame's sum in the reference's order
                 if ((rc = xfer_h2d(c, c->slot[0].d_frame, rgb[i], nfl * sizeof(float), c->stream)))
                     return rc;
                 rc = mean_luminance_reference_impl(c, c->slot[0].d_frame, w, h, sc, c->q.cs, &mean_lum[i]);

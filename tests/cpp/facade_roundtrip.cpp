@@ -94,16 +94,20 @@ int main(int argc, char **argv)
         LumaQuantizer *q = decoder.getQuantizer();
         printf("scalar %.9g %.9g %.9g %.9g\n", q->quantize(1.0f, 0), q->quantize(100.0f, 0), q->quantize(0.3f, 1),
                q->dequantize(307.0f, 0));
-        // LumaEncoderBase::initialize(file, w, h, ma, mi): the luminance range lands in attachment 436
+        // LumaEncoderBase::initialize(file, w, h, ma, mi) opens the container with a luminance range and does nothing else
+        // (reference luma_encoder.h:83-91): the encoder is not initialised by it and its parameters are untouched
         {
             LumaEncoder ranged;
-            ranged.initialize((std::string(path) + ".ranged").c_str(), 64, 32, 4000.0f, 0.02f);
+            LumaEncoderBase &base = ranged;
+            base.initialize((std::string(path) + ".ranged").c_str(), 64, 32, 4000.0f, 0.02f);
+            const bool initialisedByBase = ranged.initialized();
+            ranged.initialize((std::string(path) + ".ranged").c_str(), 64, 32);
             LumaFrame tf;
             lumaTestFrame(tf, 64, 32);
             ranged.encode(&tf);
             ranged.finish();
             LumaDecoder rd((std::string(path) + ".ranged").c_str());
-            printf("ranged %.6g %.6g\n", rd.getParams().maxLum, rd.getParams().minLum);
+            printf("ranged %d %.6g %.6g\n", (int)initialisedByBase, rd.getParams().maxLum, rd.getParams().minLum);
         }
         // error conventions
         try {

@@ -43,7 +43,7 @@ def test_facade_roundtrip_matches_oracle(oracle_mod, tmp_path, cs, bits, profile
     assert got["decoded"].split()[0] == "%016x" % o.fnv1a64(dec)
     assert "3 frames decoded" in r.stdout and "size %d" % ((1 << bits) - 1) in r.stdout
     assert got["reader"].split() == ["0.120000", "0.040000"]      # 3 frames at 25 fps, getReader()->getDuration() / getFrameDuration()
-    assert got["ranged"].split() == ["4000", "0.02"]              # initialize(file, w, h, ma, mi)
+    assert got["ranged"].split() == ["0", "10000", "0.005"]       # LumaEncoderBase::initialize(file, w, h, ma, mi): container only
     assert got["odd-size:"] == "Invalid frame size"             # src/luma_encoder.cpp:118-119
     sc = [float(x) for x in got["scalar"].split()]
     exp = [orc.quantize(1.0, 0), orc.quantize(100.0, 0), orc.quantize(0.3, 1), orc.dequantize(307.0, 0)]

@@ -172,27 +172,27 @@ inline bool endsWithNoCase(const std::string &s, const std::string &suffix)
 }
 
 // "<start>:<end>" or "<start>:<step>:<end>" (lumaenc.cpp:77-103): fields that are not given keep their defaults
+// The reference's getFrameRange (lumaenc.cpp:79-105 there), behaviour for behaviour: one or two ':' in the whole string, then
+// the numbers are read one after the other with strtol, each read starting ONE character behind the end of the previous number
+// -- whatever that character is ("1x:5" is therefore rejected: the second read starts at ":5"; "1x5:7" is accepted as 1:5).
 inline bool parseFrameRange(const std::string &spec, unsigned int &start, unsigned int &step, unsigned int &end)
 {
-    std::vector<std::string> parts;
-    size_t from = 0;
-    for (;;) {
-        const size_t c = spec.find(':', from);
-        parts.push_back(spec.substr(from, c == std::string::npos ? std::string::npos : c - from));
-        if (c == std::string::npos)
-            break;
-        from = c + 1;
-    }
-    if (parts.size() < 2 || parts.size() > 3)
+    size_t nd = 0;
+    for (char ch : spec)
+        nd += ch == ':';
+    if (nd < 1 || nd > 2)
         return false;
-    unsigned int *dst3[3] = {&start, &step, &end};
-    unsigned int *dst2[2] = {&start, &end};
-    for (size_t i = 0; i < parts.size(); i++) {
+    unsigned int *range[3] = {&start, &step, &end};
+    const char *p = spec.c_str(), *const last = p + spec.size();
+    for (size_t i = 0; i < 3; i += 3 - nd) {
+        if (p > last)
+            return false;   // (the previous number ended the string: the reference would read past its end here)
         char *stop = nullptr;
-        const long v = std::strtol(parts[i].c_str(), &stop, 10);
-        if (stop == parts[i].c_str())
+        const long v = std::strtol(p, &stop, 10);
+        if (stop == p)
             return false;
-        *(parts.size() == 3 ? dst3[i] : dst2[i]) = (unsigned int)v;
+        *range[i] = (unsigned int)v;
+        p = stop + 1;
     }
     return true;
 }
