@@ -76,10 +76,11 @@ int lumahip_sync(lumahip_ctx *ctx);
  * count of lumahip_begin_unordered), "lane_grid_enc" / "lane_grid_dec" (workgroups per launch inside an unordered section,
  * 0 = rule), "copy_threads" (worker threads that copy pageable caller memory into the pinned staging chunks of the _host
  * entry points: 0..32, default 3), "host_bands" (row bands the single-frame _host entry points split a frame into so that
- * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "ycbcr_tables" (0: the
+ * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "band_taper" (each band's rows in
+ * per cent of the previous band's, 10..100, default 70: the last band is small, so little is left to do once the upload ends), "ycbcr_tables" (0: the
  * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
  * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
- * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_YCBCR_TABLES set the
+ * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_BAND_TAPER, LUMAHIP_YCBCR_TABLES set the
  * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
 int lumahip_tune(lumahip_ctx *ctx, const char *key, long value);
 

@@ -66,7 +66,7 @@ def build_library(force: bool = False, nofastdiv: bool = False) -> str:
 
 
 KERNEL_SOURCES = ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_internal.hpp", "lumahip_core.hip",
-                  "lumahip_encode.hip", "lumahip_decode.hip", "lumahip_misc.hip", "lut_index.cpp", "Makefile")
+                  "lumahip_encode.hip", "lumahip_decode.hip", "lumahip_misc.hip", "lut_index.cpp", "flags.mk")
 
 
 def kernel_source_sha() -> str:

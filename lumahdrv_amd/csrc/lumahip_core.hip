@@ -67,7 +67,7 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_LDS_TABLE_MAX_KB", "lds_table_max_kb"},
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
-                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
+                                              {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_BAND_TAPER", "band_taper"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
                                               {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
@@ -256,6 +256,10 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         if (v < 1 || v > lumahip_ctx::MAX_BANDS)
             return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
         c->host_bands = (int)v;
+    } else if (k == "band_taper") {
+        if (v < 10 || v > 100)
+            return fail(c, LUMAHIP_ERR_ARG, "band_taper must be 10..100 (per cent)");
+        c->band_taper = (int)v;
     } else if (k == "copy_spin") {
         c->copy_spin = v > 0 ? (int)std::min<long>(v, 10000000) : 0;
         lumahip_copy_pool_destroy(c->copy_pool);
@@ -626,34 +630,40 @@ bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nf
 
 // Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  The default is 2048 threads' worth per CU (8
 // workgroups of 256), i.e. MORE than are resident at once for most kernels: the surplus is dispatched as resident ones
-// retire, which evens out the tail of short launches.  The rules below are for long (batched) launches, each one found by
-// running both settings in one process (tools/ab_inproc.py).  LUMAHIP_GRID_ENC / LUMAHIP_GRID_DEC (absolute) and
-// LUMAHIP_BLOCKS_PER_CU (per CU, both directions) are measurement overrides.
+// retire, which evens out the tail of short launches.  The rules below were found on 20 x 3840x2160 launches by running both
+// settings in one process (tools/ab_inproc.py, profiles/r02_grid_sweep.txt) and then re-derived over {720p, 1080p, 4K, 8K} x
+// {1, 2, 4, 8, 20, 50 frames} x {Lu'v', YCbCr} x {encode, decode} with every setting interleaved in one process
+// (tools/launch_rules_sweep.py, profiles/r03_launch_rules.txt: before / after tables).  lumahip_tune "grid_enc" / "grid_dec"
+// (absolute) and "blocks_per_cu" (per CU, both directions) are measurement overrides.
 int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers, bool ycbcr)
 {
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
+    const bool rule = c->blocks_per_cu == 0;
     // The 4:2:0 16-bit decode kernels write 12 of their 15 bytes per pixel, and fewer concurrent writers suit the memory
-    // system better: 5 workgroups of 256 threads per CU instead of 8 is 2.7-3.6 % faster on batched launches, both builds
-    // in one process (profiles/r02_grid_sweep.txt; the same change is 4 % SLOWER for 4:4:4 Lu'v' and 10 % slower for the
-    // 8-bit profiles, so it is theirs only).  Only where the launch is long enough for the coarser tail not to matter.
-    if (few_writers && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 12L * c->num_cu * 5)
-        per_cu = 5;
+    // system better than the default 8 workgroups of 256 threads per CU: 5 per CU on long launches (20 x 4K: 455 us against
+    // 483; 8K x4 and longer likewise), 6 per CU on medium ones (1080p x8 ... x50, 4K x2 ... x8, 8K x1 ... x2: 2-5 % faster
+    // than either 5 or 8), the default below that, where the finer tail matters more.  (The same change is 4 % SLOWER for
+    // 4:4:4 Lu'v' and 10 % slower for the 8-bit profiles, so it is theirs only.)
+    if (few_writers && rule && threads == 256) {
+        if (total_tiles >= 60000)
+            per_cu = 5;
+        else if (total_tiles >= 6000)
+            per_cu = 6;
+    }
     // The encode kernels with 256-thread workgroups (tables up to 32 KiB; not YCbCr, which is VALU-bound and wants the
-    // waves) run 3-6 % faster on long launches with 3 workgroups per CU than with 8 -- every colour space / profile
-    // variant, same build in one process (tools/ab_encode_grid.sh, profiles/r02_grid_sweep.txt); 6 per CU is 9 % SLOWER,
-    // 4 about as good as 3.  Fewer resident waves draw less power at the package limit and keep fewer streams open in the
-    // memory system.  Short launches keep 8 per CU for their tail.
-    if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && total_tiles >= 40L * c->num_cu * 3)
+    // waves) run fastest with 3 workgroups per CU -- on long launches 3-6 % faster than with 8 (every colour space /
+    // profile variant, profiles/r02_grid_sweep.txt; 6 per CU is 9 % SLOWER, 4 about as good), and the sweep over shapes shows
+    // the same from one 1080p frame upwards (4K x1: 27.5 us against 28.0 with 4 and 29.4 with 8; 4K x4: 90.5 / 93.8 / 97.1;
+    // 720p frames: no difference).  Fewer resident waves draw less power at the package limit and keep fewer streams open
+    // in the memory system.
+    if (dir == 0 && rule && threads == 256 && !ycbcr)
         per_cu = 3;
-    // ... and single frames with 4 per CU (profiles/r03_single_frame.txt: 1080p 12.7 against 13.2 us, 4K 28.2 against 30.0;
-    // 2 per CU is no better, and the decode kernels want their 8)
-    else if (dir == 0 && c->blocks_per_cu == 0 && threads == 256 && !ycbcr)
-        per_cu = 4;
     // The YCbCr kernels are VALU-bound and only three of their 512-thread workgroups (49 KiB of LDS each) are resident
-    // per CU: many more, smaller static shares balance the CUs better than one share per resident workgroup -- 18 per CU
-    // is 4.9 % faster than 4 for encode, 12 per CU 4.3 % for decode (same build in one process, profiles/r02_grid_sweep.txt).
-    if (ycbcr && c->blocks_per_cu == 0 && threads == 512 && total_tiles >= 8L * c->num_cu * 18)
-        per_cu = dir == 0 ? 18 : 12;
+    // per CU: many more, smaller static shares balance the CUs better than one share per resident workgroup.  12 per CU is
+    // never slower than the default 4 and 3-8 % faster from a few 1080p frames upwards; the longest launches gain another
+    // 1-2 % from 18 (encode from 18 4K frames on, decode from 40).
+    if (ycbcr && rule && threads == 512)
+        per_cu = total_tiles >= (dir == 0 ? 36000 : 80000) ? 18 : 12;
     long g = (long)c->num_cu * per_cu;
     // Inside an unordered section every launch keeps the grid it would have alone: two lanes of 3 (encode) / 5 (decode)
     // workgroups per CU each measured best (profiles/r03_layout_lab.txt: encode 0.780 of the roofline against 0.751 ordered,

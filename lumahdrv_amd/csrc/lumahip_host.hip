@@ -206,12 +206,18 @@ static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, si
     if (!flat && dp > XFER_CHUNK)
         return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
     const size_t total = flat ? width * rows : rows;                 // bytes or rows
-    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;          // per chunk
     for (size_t done = 0; done < total;) {
         lumahip_ctx::Stage &st = c->stage_up[c->up_next++ % lumahip_ctx::N_STAGE];
         int rc = stage_ready(c, st);
         if (rc)
             return rc;
+        // The first chunks of a call are small (1, 2, 4 MiB, then whole chunks): the copy engine starts after 15 us of
+        // staging instead of after the 110 us a whole chunk takes to fill, and nothing of that lead is lost later because the
+        // DMA of a chunk (150 us) takes longer than filling the next one.
+        size_t cap = XFER_CHUNK;
+        if (c->up_ramp < 3)
+            cap = std::min(cap, (size_t)1 << (20 + c->up_ramp++));
+        const size_t per = flat ? cap : std::max<size_t>(1, cap / dp);   // bytes or rows per chunk
         const size_t n = total - done < per ? total - done : per;
         size_t bytes;
         if (flat) {
@@ -368,18 +374,37 @@ static int pipe_streams(lumahip_ctx *c);
 // One host frame per call is PCIe time: 99.5 MB up at ~56 GB/s (1.76 ms), 30 us of kernel, 24.9 MB down (0.45 ms); done one
 // after the other that is 2.2 ms pinned and more staged (profiles/r03_hostfed_lab.txt).  Rows are independent (pairs of rows
 // in 4:2:0), so a large frame is cut into `host_bands` bands of rows: band k+1 goes up while band k is transformed and band
-// k-1 comes down -- the link is full duplex -- and the call is bound by the larger of the two directions.  Bands are whole
-// tiles of the kernels (multiples of 8 rows), so every pixel sees exactly the arithmetic of the unbanded launch.
-static int band_rows(const lumahip_ctx *c, unsigned w, unsigned h, int &nb)
+// k-1 comes down -- the link is full duplex -- and the call is bound by the upload plus whatever is left to do for the LAST
+// band once its rows have arrived (its kernel, its download, the copy out of the staging chunks).  The bands therefore
+// TAPER: each is `band_taper` % of the previous one (default 70: 39.5 / 27.6 / 19.3 / 13.5 % of the rows for four bands), so that
+// tail is an eighth of the frame instead of a quarter (rocprofv3 timeline of the uniform split: 0.5 ms of 2.67 ms per
+// pageable 4K frame after the last upload chunk; profiles/r03_hostfed_timeline.txt).  A download still fits under the next
+// band's upload: it moves a quarter of the bytes.  Bands are multiples of 16 rows (whole tiles of every kernel variant); the
+// pixel arithmetic does not depend on the split.
+static int band_plan(const lumahip_ctx *c, unsigned w, unsigned h, unsigned r0[lumahip_ctx::MAX_BANDS + 1])
 {
-    nb = c->host_bands;
+    int nb = c->host_bands;
     if ((size_t)w * h < (size_t)1 << 20 || nb < 2)      // small frames: latency, not bandwidth
         nb = 1;
-    int hb = (int)(((h + nb - 1) / nb + 7) & ~7u);
-    if (hb < 64)
-        hb = 64;
-    nb = (int)((h + hb - 1) / hb);
-    return hb;
+    const double q = c->band_taper / 100.0;
+    double wsum = 0.0, wk = 1.0;
+    for (int k = 0; k < nb; k++, wk *= q)
+        wsum += wk;
+    unsigned row = 0;
+    int k = 0;
+    wk = 1.0;
+    r0[0] = 0;
+    for (int i = 0; i < nb && row < h; i++, wk *= q) {
+        unsigned rows = (unsigned)(h * (wk / wsum) + 0.5);
+        rows = (rows + 15) & ~15u;
+        if (rows < 64)
+            rows = 64;
+        if (i == nb - 1 || row + rows > h || h - (row + rows) < 64)   // the last band takes what is left
+            rows = h - row;
+        row += rows;
+        r0[++k] = row;
+    }
+    return k;   // number of bands; band i = rows [r0[i], r0[i+1])
 }
 
 static int band_events(lumahip_ctx *c, int nb)
@@ -404,6 +429,7 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    c->up_ramp = 0;
     const int bps = profile > 1 ? 2 : 1;
     PlaneLayout L;
     plane_layout(L, w, h, profile, stride);
@@ -422,8 +448,8 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
     const size_t pfs[3] = {0, 0, 0};
     const size_t n1 = (size_t)w * h;
     const bool sub = (profile == 0 || profile == 2);
-    int nb = 1;
-    const int hb = band_rows(c, w, h, nb);
+    unsigned band0[lumahip_ctx::MAX_BANDS + 1];
+    const int nb = band_plan(c, w, h, band0);
     float st[3] = {0.0f, __builtin_inff(), -__builtin_inff()};
     if (nb > 1) {
         if ((rc = pipe_streams(c)) || (rc = band_events(c, nb)))
@@ -431,7 +457,7 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         HIPCHK(c, hipStreamSynchronize(c->stream));   // the bands run on the pipeline streams: after everything queued so far
         hipStream_t saved = c->stream;
         auto fetch = [&](int k) -> int {              // planes rows of band k, after its kernel
-            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             HIPCHK(c, hipStreamWaitEvent(c->s_d2h, c->band_kern[k], 0));
             for (int p = 0; p < 3; p++) {
                 const unsigned pr0 = (p && sub) ? r0 / 2 : r0, prow = (p && sub) ? rows / 2 : rows;
@@ -442,7 +468,7 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
             return LUMAHIP_OK;
         };
         for (int k = 0; k < nb && rc == LUMAHIP_OK; k++) {
-            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             const size_t roff = (size_t)r0 * w;
             for (int ch = 0; ch < 3 && rc == LUMAHIP_OK; ch++)
                 rc = xfer_h2d(c, c->d_frame + ch * n1 + roff, rgb + ch * n1 + roff, (size_t)rows * w * sizeof(float), c->s_h2d);
@@ -529,6 +555,7 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    c->up_ramp = 0;
     PlaneLayout L;
     plane_layout(L, w, h, profile, stride);
     for (int p = 0; p < 3; p++)
@@ -543,15 +570,15 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
     const size_t pfs[3] = {0, 0, 0};
     const size_t n1 = (size_t)w * h;
     const bool sub = (profile == 0 || profile == 2);
-    int nb = 1;
-    const int hb = band_rows(c, w, h, nb);
+    unsigned band0[lumahip_ctx::MAX_BANDS + 1];
+    const int nb = band_plan(c, w, h, band0);
     if (nb > 1) {
         if ((rc = pipe_streams(c)) || (rc = band_events(c, nb)))
             return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipStream_t saved = c->stream;
         auto fetch = [&](int k) -> int {              // float rows of band k, after its kernel
-            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             const size_t roff = (size_t)r0 * w;
             HIPCHK(c, hipStreamWaitEvent(c->s_d2h, c->band_kern[k], 0));
             for (int ch = 0; ch < 3; ch++)
@@ -560,7 +587,7 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
             return LUMAHIP_OK;
         };
         for (int k = 0; k < nb && rc == LUMAHIP_OK; k++) {
-            const unsigned r0 = (unsigned)k * hb, rows = std::min<unsigned>(hb, h - r0);
+            const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             const size_t roff = (size_t)r0 * w;
             const unsigned char *bp[3];
             for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++) {

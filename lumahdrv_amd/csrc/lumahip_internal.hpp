@@ -88,6 +88,8 @@ struct lumahip_ctx {
     hipEvent_t band_h2d[MAX_BANDS] = {}, band_kern[MAX_BANDS] = {};
     float *d_band_stats = nullptr;  // 3 floats per band
     int host_bands = 4;             // lumahip_tune("host_bands"): 1 = the whole frame in one piece
+    int band_taper = 70;            // lumahip_tune("band_taper"): each band's rows in % of the previous band's (100 = uniform)
+    int up_ramp = 0;                // staged uploads: how many of the small leading chunks of this call have been used
     size_t h_stats_cap = 0;
 
     // Pinned staging for pageable caller memory (see xfer_h2d): two chunks per direction, ping-pong

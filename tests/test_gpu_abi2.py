@@ -209,6 +209,36 @@ def test_copy_threads_do_not_change_results(oracle_mod, threads):
     c.close()
 
 
+@pytest.mark.parametrize("bands,taper", [(1, 100), (4, 100), (4, 70), (8, 40), (3, 10), (5, 55)])
+def test_row_bands_do_not_change_results(oracle_mod, bands, taper):
+    """The single-frame _host entry points cut large frames into tapering row bands (upload | kernel | download overlap):
+    every split -- one piece, uniform, tapered, more bands than fit, heights that are not multiples of the 16-row band
+    unit -- must give the oracle's bytes, encode and decode, Lu'v' and YCbCr, with the mean luminance of the whole frame."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    for cfg, sc in (((L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005), 1.0), ((L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01), 20.0)):
+        c = L.Context(0)
+        c.tune("host_bands", bands)
+        c.tune("band_taper", taper)
+        c.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+        orc = o.Oracle(*cfg)
+        for (w, h) in ((1922, 1082), (2048, 514), (1026, 1100)):     # >= 2^20 pixels: banded; 514 rows: fewer bands than asked
+            f = o.synth_frame(w, h, 11, bands)
+            planes, st, mean = c.encode_frame(f, sc, 2)
+            e, st2, emean = orc.encode(f.copy(), sc, 2)
+            assert tuple(st2) == tuple(st) and all(np.array_equal(a, b) for a, b in zip(planes, e)), (cfg, w, h)
+            assert abs(mean - emean) <= 0.02 * abs(emean) + 1e-6       # (the oracle sums sequentially in fp32, as the reference does)
+            dec = c.decode_frame(planes, st, w, h, sc, 2)
+            assert np.array_equal(dec.view(np.uint32), orc.decode(e, st, w, h, sc, 2).view(np.uint32)), (cfg, w, h)
+        c.close()
+    with pytest.raises(L.LumaHipError):
+        c2 = L.Context(0)
+        try:
+            c2.tune("band_taper", 5)
+        finally:
+            c2.close()
+
+
 def _build_cpp(tmp, name):
     exe = os.path.join(tmp, name)
     lib = os.path.join(ROOT, "lumahdrv_amd", "lib")

@@ -38,6 +38,13 @@ def main():
         for b in range(n):
             pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
             ctx.decode_frames_device(pl, st, psz, B, w, h, 2, sc, out.data_ptr() + b * B * n3 * 4, n3)
+    # the traffic-only probes (same loads and stores, no arithmetic): known byte counts in the kernels' own access patterns,
+    # i.e. the calibration of FETCH_SIZE / WRITE_SIZE the microarchitecture guide asks for (they overwrite planes / frames)
+    for b in range(n):
+        pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
+        o = out.data_ptr() + b * B * n3 * 4
+        ctx.probe_decode_traffic(pl, st, psz, B, w, h, [o + k * w * h * 4 for k in range(3)], n3, 1)
+        ctx.probe_encode_traffic(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, pl, st, psz, 1)
     torch.cuda.synchronize()
     print("prof_driver done: %d launches each of encode/decode, %d pixels per launch" % (2 * n, B * w * h))
 

@@ -14,6 +14,9 @@ P="rocprofv3 --kernel-trace --output-format csv"
 BARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-other-workloads --min-seconds 0.3 --workload $WL"
 $P --stats -d $OUT/stats -o bench -- python bench.py $BARGS > $OUT/bench_under_rocprof.log 2>&1
 python bench.py $BARGS > $OUT/bench_plain.log 2>&1
+# the same K launches back to back on ONE stream: per-kernel durations in this trace are directly comparable with bench.py's
+# kernel_ms_ordered (with two lanes two launches are in flight and each one's own duration is about twice the window / K)
+$P --stats -d $OUT/stats_ordered -o bench -- python bench.py $BARGS --lanes 0 > $OUT/bench_ordered_under_rocprof.log 2>&1
 $P --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o p -- python tools/prof_driver.py 3 $WL > $OUT/pmc_fetch.log 2>&1
 $P --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o p -- python tools/prof_driver.py 3 $WL > $OUT/pmc_write.log 2>&1
 $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_inst -o p -- python tools/prof_driver.py 3 $WL > $OUT/pmc_inst.log 2>&1

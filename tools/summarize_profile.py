@@ -52,23 +52,70 @@ def update_json(path, wl, entry):
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
 
 
+def capture_sha(src):
+    """the kernel-source SHA the capture RAN on: bench.py prints it in its JSON line (never the SHA of the local tree)"""
+    line = [l for l in open(os.path.join(src, "bench_plain.log")).read().splitlines() if l.startswith('{"metric"')][-1]
+    return json.loads(line).get("kernel_source_sha")
+
+
+def launch_windows(trace_csv, pattern):
+    """From a rocprofv3 kernel trace: the dispatches of one kernel grouped into back-to-back runs (gaps < 30 us) of >= 5
+    launches.  Per run: whether its launches overlap each other (two lanes of an unordered section) and the run's span /
+    number of launches -- the profiler-side counterpart of bench.py's `kernel_ms` (hipEvent window / K)."""
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace_csv))
+                if pattern in r["Kernel_Name"])
+    out = {"isolated_us": [], "ordered_us": [], "ordered_span_us": [], "overlapped_us": [], "overlapped_span_us": []}
+    runs, cur = [], []
+    for k in ks:
+        if cur and k[0] - max(e for _, e in cur) >= 30000:
+            runs.append(cur)
+            cur = []
+        cur.append(k)
+    if cur:
+        runs.append(cur)
+    for run in runs:
+        if len(run) < 5:
+            out["isolated_us"] += [(e - b) / 1e3 for b, e in run]
+            continue
+        nov = sum(1 for i in range(1, len(run)) if run[i][0] < run[i - 1][1])
+        kind = "overlapped" if nov > len(run) // 2 else "ordered"
+        out[kind + "_us"] += [(e - b) / 1e3 for b, e in run]
+        out[kind + "_span_us"].append((max(e for _, e in run) - run[0][0]) / 1e3 / len(run))
+    return out
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else float("nan")
+
+
 def main():
     from lumahdrv_amd import capi
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    wl = sys.argv[2] if len(sys.argv) > 2 else "pq11_luv"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = args[0] if len(args) > 0 else "r03"
+    wl = args[1] if len(args) > 1 else "pq11_luv"
     src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    sha = capi.kernel_source_sha()
+    sha = capture_sha(src)
+    if sha != capi.kernel_source_sha():
+        print("NOTE: the capture ran on kernel sources %s, the local tree is %s: bench.py will not report these figures "
+              "until the tree matches again" % (sha, capi.kernel_source_sha()))
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
     except Exception:
         commit = "?"
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
-    for f in ("bench_plain.log", "bench_under_rocprof.log"):
+    if os.path.exists(os.path.join(src, "stats_ordered", "bench_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "stats_ordered", "bench_kernel_stats.csv"),
+                    os.path.join(dst, "%s_%s_kernel_stats_ordered.csv" % (tag, wl)))
+    for f in ("bench_plain.log", "bench_under_rocprof.log", "bench_ordered_under_rocprof.log"):
+        if not os.path.exists(os.path.join(src, f)):
+            continue
         line = [l for l in open(os.path.join(src, f)).read().splitlines() if l.startswith('{"metric"')][-1]
         open(os.path.join(dst, "%s_%s_%s" % (tag, wl, f.replace(".log", ".json"))), "w").write(line + "\n")
-    B, w, h = 20, 3840, 2160
+    shape = json.load(open(os.path.join(src, "shape.json"))) if os.path.exists(os.path.join(src, "shape.json")) else {}
+    B, w, h = shape.get("frames", 20), shape.get("width", 3840), shape.get("height", 2160)
     px = B * w * h
     c = {}
     for grp in ("fetch", "write", "inst", "wait", "mix1", "mix2"):
@@ -77,21 +124,35 @@ def main():
             continue
         for k, d in load(p).items():
             c.setdefault(k, {}).update(d)
-    enc = next(k for k in c if "k_encode" in k)
-    dec = next(k for k in c if "k_decode" in k)
+    enc = next(k for k in c if "k_encode<" in k)
+    dec = next(k for k in c if "k_decode<" in k)
     syn = next((k for k in c if "k_synth" in k), None)
+    eprobe = next((k for k in c if "k_encode_traffic_probe" in k), None)
+    dprobe = next((k for k in c if "k_decode_traffic_probe" in k), None)
     lines = ["# %s PMC summary -- workload %s, %d x %dx%d frames per launch (tools/prof_driver.py)" % (tag, wl, B, w, h), "",
-             "rocprofv3 --pmc, one run per counter group; per-launch averages.  Kernel sources %s, commit %s." % (sha, commit), ""]
+             "rocprofv3 --pmc, one run per counter group; per-launch averages.  Kernel sources %s (the SHA the capture ran on), "
+             "summarised at commit %s." % (sha, commit), ""]
     alg = {"enc_r": 12.0 * px, "enc_w": 3.0 * px, "dec_r": 3.0 * px, "dec_w": 12.0 * px}
-    mixes = {}
-    for name, k, r_alg, w_alg in (("encode", enc, alg["enc_r"], alg["enc_w"]), ("decode", dec, alg["dec_r"], alg["dec_w"])):
+    # calibration on the traffic-only probes: same access pattern, known byte counts
+    cal = {"enc_r": 2.0, "enc_w": 1.0, "dec_r": 2.0, "dec_w": 1.0}
+    cal_src = {k: "guide (gfx950: FETCH_SIZE x 2 for wide loads; WRITE_SIZE as reported)" for k in cal}
+    for probe, r_key, w_key in ((eprobe, "enc_r", "enc_w"), (dprobe, "dec_r", "dec_w")):
+        if probe and "FETCH_SIZE" in c[probe] and "WRITE_SIZE" in c[probe]:
+            cal[r_key] = alg[r_key] / (c[probe]["FETCH_SIZE"] * 1024)
+            cal[w_key] = alg[w_key] / (c[probe]["WRITE_SIZE"] * 1024)
+            cal_src[r_key] = cal_src[w_key] = "measured on `%s` in the same run" % probe
+    mixes, traffic = {}, {}
+    for name, k, r_key, w_key in (("encode", enc, "enc_r", "enc_w"), ("decode", dec, "dec_r", "dec_w")):
         d = c[k]
         lines += ["## %s: `%s`" % (name, k), "", "| counter | per launch |", "|---|---|"]
         lines += ["| %s | %.4g |" % (cn, v) for cn, v in sorted(d.items())]
         fetch, write = d["FETCH_SIZE"] * 1024, d["WRITE_SIZE"] * 1024
+        traffic[name] = cal[r_key] * fetch + cal[w_key] * write
         valu_px = d["SQ_INSTS_VALU"] * 64 / px
-        lines += ["", "* FETCH_SIZE %.4g B raw (x2 = %.4g B) vs algorithmic read %.4g B; WRITE_SIZE %.4g B vs algorithmic write %.4g B"
-                  % (fetch, 2 * fetch, r_alg, write, w_alg),
+        lines += ["", "* FETCH_SIZE %.4g B raw, x %.4f (%s) = %.4g B vs algorithmic read %.4g B; WRITE_SIZE %.4g B x %.4f = %.4g B vs "
+                  "algorithmic write %.4g B" % (fetch, cal[r_key], cal_src[r_key], cal[r_key] * fetch, alg[r_key], write, cal[w_key],
+                                              cal[w_key] * write, alg[w_key]),
+                  "* HBM traffic per launch = %.5g B = %.4f x algorithmic (15 B x %d px)" % (traffic[name], traffic[name] / (15.0 * px), px),
                   "* VALU instructions per pixel: %.1f; LDS instructions per pixel: %.2f; waves: %d"
                   % (valu_px, d["SQ_INSTS_LDS"] * 64 / px, d["SQ_WAVES"]),
                   "* wave time split: active %.0f %%, waiting on memory/LDS counters (SQ_WAIT_ANY) %.0f %%, issue-stalled %.0f %%"
@@ -112,25 +173,61 @@ def main():
                          d.get("SQ_INSTS_VALU_INT32", 0) * 64 / px, fp64 * 64 / px, d.get("SQ_INSTS_VALU_CVT", 0) * 64 / px,
                          d.get("SQ_INSTS_VALU_TRANS_F32", 0) * 64 / px, other * 64 / px, cyc * 64 / px, cyc / max(d["SQ_INSTS_VALU"], 1))]
         lines += [""]
+    lines += ["## calibration", ""]
     if syn and "WRITE_SIZE" in c[syn]:
-        lines += ["## calibration: `lh::k_synth` writes 3 x %d x %dx%d x 4 B = %.4g B with 4-B stores; WRITE_SIZE reports %.4g B"
-                  % (3 * B, w, h, 3 * B * 3 * w * h * 4.0, c[syn]["WRITE_SIZE"] * 1024), ""]
-    e = c[enc]
-    traffic = 2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024
+        lines += ["* `lh::k_synth` (4-B stores): WRITE_SIZE reports %.5g B per launch" % (c[syn]["WRITE_SIZE"] * 1024)]
+    for probe, what in ((eprobe, "12 B read (16 B/lane loads) + 3 B written per pixel"), (dprobe, "3 B read (8 / 4 B per lane loads) + 12 B written per pixel")):
+        if probe and "FETCH_SIZE" in c[probe]:
+            lines += ["* `%s` (%s, known byte counts): FETCH_SIZE %.5g B, WRITE_SIZE %.5g B" % (probe, what, c[probe]["FETCH_SIZE"] * 1024, c[probe].get("WRITE_SIZE", 0) * 1024)]
+    lines += [""]
+    # ---- kernel durations under the profiler against bench.py's own clock
+    tr_csv = os.path.join(src, "stats", "bench_kernel_trace.csv")
+    if os.path.exists(tr_csv):
+        lines += ["## kernel durations in the rocprofv3 kernel trace of `python bench.py` (the same command, under the profiler)", "",
+                  "bench.py times a region of K launches with a hipEvent pair and reports window / K (`kernel_ms`).  By default the K",
+                  "launches of a region run in an unordered section (two lanes), so two launches are in flight and each one's OWN",
+                  "duration in the trace is about twice the per-launch window; the `*_ordered` legs of the same run are K launches back",
+                  "to back on one stream, whose trace durations are directly comparable with `kernel_ms_ordered`.", "",
+                  "| kernel | launches | ordered: median duration | ordered: span / launches | overlapped: median duration | overlapped: span / launches | isolated launches: median |",
+                  "|---|---|---|---|---|---|---|"]
+        for name, pat in (("encode", "k_encode<"), ("decode", "k_decode<")):
+            wv = launch_windows(tr_csv, pat)
+            lines += ["| %s | %d | %.1f us | %.1f us | %.1f us | %.1f us | %.1f us |"
+                      % (name, sum(len(wv[k]) for k in ("isolated_us", "ordered_us", "overlapped_us")), med(wv["ordered_us"]),
+                         med(wv["ordered_span_us"]), med(wv["overlapped_us"]), med(wv["overlapped_span_us"]), med(wv["isolated_us"]))]
+        for f, label in (("bench_under_rocprof.log", "under rocprofv3"), ("bench_plain.log", "same box, no profiler")):
+            try:
+                line = [l for l in open(os.path.join(src, f)).read().splitlines() if l.startswith('{"metric"')][-1]
+                j = json.loads(line)
+                rf, drf = j["roofline"], j.get("decode_roofline", {})
+                drf = drf.get("hbm", drf)
+                lines += ["", "bench.py %s: encode kernel_ms %.4f (ordered %s, isolated %s), decode kernel_ms %s (ordered %s)"
+                          % (label, rf["kernel_ms"], rf.get("kernel_ms_ordered"), rf.get("kernel_ms_isolated_launch"),
+                             drf.get("kernel_ms"), drf.get("kernel_ms_ordered"))]
+            except Exception:
+                pass
+        lines += ["", "(The profiler serialises part of the dispatch of concurrent queues, so the overlapped span per launch it sees is",
+                  "longer than in the unprofiled run; the ordered figures agree with bench.py's to a fraction of a per cent.)", ""]
     lines += ["## roofline.traffic", "",
-              "encode HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = %.5g B; algorithmic = 15 B x %d px = %.5g B (ratio %.3f)"
-              % (traffic, px, 15.0 * px, traffic / (15.0 * px)), ""]
+              "encode HBM bytes per launch = %.5g B; algorithmic = 15 B x %d px = %.5g B (ratio %.4f)"
+              % (traffic["encode"], px, 15.0 * px, traffic["encode"] / (15.0 * px)),
+              "decode HBM bytes per launch = %.5g B (ratio %.4f)" % (traffic["decode"], traffic["decode"] / (15.0 * px)), ""]
     open(os.path.join(dst, "%s_%s_pmc_summary.md" % (tag, wl)), "w").write("\n".join(lines))
+    e, dd = c[enc], c[dec]
     update_json(os.path.join(dst, "traffic_latest.json"), wl,
                 {"tag": tag, "workload": wl, "kernel_source_sha": sha, "commit": commit, "pixels_per_launch": float(px),
-                 "hbm_bytes_per_launch": traffic, "fetch_size_bytes_raw": e["FETCH_SIZE"] * 1024,
-                 "write_size_bytes": e["WRITE_SIZE"] * 1024,
-                 "note": "2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, separate passes (tools/profile_round.sh)"})
+                 "hbm_bytes_per_launch": traffic["encode"], "decode_hbm_bytes_per_launch": traffic["decode"],
+                 "fetch_size_bytes_raw": e["FETCH_SIZE"] * 1024, "write_size_bytes": e["WRITE_SIZE"] * 1024,
+                 "decode_fetch_size_bytes_raw": dd["FETCH_SIZE"] * 1024, "decode_write_size_bytes": dd["WRITE_SIZE"] * 1024,
+                 "calibration": {k: round(v, 5) for k, v in cal.items()},
+                 "note": "cal_r * FETCH_SIZE + cal_w * WRITE_SIZE, rocprofv3 PMC, separate passes (tools/profile_round.sh); calibration "
+                         "factors measured on the traffic-only probes of the same access patterns in the same run (guide: x2 for "
+                         "wide loads on gfx950)"})
     if "encode" in mixes:
         update_json(os.path.join(dst, "valu_mix_latest.json"), wl,
-                    dict(mixes["encode"], tag=tag, workload=wl, kernel_source_sha=sha, commit=commit,
+                    dict(mixes["encode"], tag=tag, workload=wl, kernel_source_sha=sha, commit=commit, decode=mixes.get("decode"),
                          note="PMC class counters x issue costs of tools/valu_bench.hip (tools/summarize_profile.py)"))
-    print("\n".join(lines[-14:]))
+    print("\n".join(lines[-24:]))
 
 
 if __name__ == "__main__":
