@@ -242,7 +242,9 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
     psz = [hs[p] * st[p] for p in range(3)]
     per_frame = n3 * 4 * 2 + sum(psz)                      # input + decoded output + planes
     free, _total = torch.cuda.mem_get_info(dev)
-    want_frames = 500 if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)    # >= 4 GB of distinct input: >> 256 MB MALL
+    # main: configs[1]'s 500 frames (49.8 GB of input at 4K; larger frames: as many as the same bytes hold); others: >= 4 GB of
+    # distinct input, >> the 256 MB MALL
+    want_frames = min(500, max(B, int(50e9 // (n3 * 4)) // B * B)) if main else max(8 * B, int(4e9 // (n3 * 4)) // B * B)
     striped = False
     if pool is not None:
         from lumahdrv_amd.placement import CHUNK_BYTES, slots
@@ -680,7 +682,7 @@ def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True
         spc, _ = slots(CHUNK_BYTES, B * n1 * 4)
         if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
             return None
-        nb = nbatches if nbatches else 500 // B            # default: the 500-frame stream, input + decoded output
+        nb = nbatches if nbatches else min(500 // B, max(1, int(50e9 // (B * n3 * 4))))   # default: the 500-frame stream (4K), input + decoded output
         stripe = with_output and args.decode_layout == "auto" and spc >= 1
         n_float = nb * (2 if (with_output and not stripe) else 1)
         n_y, n_uv, n_striped = -(-nb // ypc), -(-nb // uvpc), (-(-nb // spc) if stripe else 0)
@@ -699,16 +701,28 @@ def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True
         return None
 
 
-def facade_hostfed(w, h):
+def facade_hostfed(w, h, runs=3):
     """LumaEncoder::encode(LumaFrame*) end to end on HOST frames (tools/facade_hostfed.cpp, the C++ facade): H2D + kernel +
-    D2H per call -- the reference's drop-in call as its own callers make it.  PCIe-bound; reported beside, never as, `value`."""
+    D2H per call -- the reference's drop-in call as its own callers make it.  PCIe-bound; reported beside, never as, `value`.
+    Its own process, run BEFORE this process allocates device memory: for a few seconds after a process has handed tens of GB
+    back to the driver (the chunk pool does, and so does the end of every leg), latency-bound work like one frame per call
+    runs ~35 % slower (profiles/r03_settle.txt).  Median of `runs` short runs: the GPU boxes' hosts are shared."""
     exe = os.path.join(ROOT, "lumahdrv_amd", "bin", "facade_hostfed")
     try:
-        out = subprocess.run([exe, str(w), str(h), "24"], capture_output=True, text=True, timeout=300)
-        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-        d = json.loads(line)
+        got = []
+        for _ in range(runs):
+            out = subprocess.run([exe, str(w), str(h), "16"], capture_output=True, text=True, timeout=300)
+            got.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+        d = dict(got[0])
+        for k in got[0]:
+            if isinstance(got[0][k], float):
+                d[k] = float(np.median([g[k] for g in got]))
+        d["frames"] = got[0]["frames"]
+        d["runs"] = runs
+        d["pageable_runs"] = [g["LumaEncoder_encode_pageable_frame"] for g in got]
         d["what"] = ("host frames through the C++ facade, one frame per call, synchronous (H2D 12 B/px + fused kernel + D2H 3 B/px); "
-                     "pageable = plain new float[] as the reference's LumaFrame, staged by the context's copy threads")
+                     "pageable = plain new float[] as the reference's LumaFrame, staged by the context's copy threads; median of "
+                     "%d runs made before this process touched the GPU" % runs)
         return d
     except Exception as e:
         return {"error": repr(e)}
@@ -762,6 +776,8 @@ def main():
         res = run_stream(L, args, rank, n_gpus, local_rank, use_dist, dev)
     else:
         w, h, B, K, Wm = args.width, args.height, args.frames_per_step, args.steps, args.warmup
+        # the host-fed leg first: its own process on a GPU this process has not allocated anything on yet (facade_hostfed says why)
+        hostfed = facade_hostfed(w, h) if (rank == 0 and n_gpus == 1 and not args.no_facade_hostfed) else None
         pool = make_pool(L, args, dev, local_rank, w, h, B)
         r, cfg = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, True, sha, pool)
         res = {
@@ -806,8 +822,8 @@ def main():
             res["other_workloads"] = others
         if pool is not None:
             pool.close()
-        if rank == 0 and n_gpus == 1 and not args.no_facade_hostfed:
-            res["facade_hostfed"] = facade_hostfed(w, h)
+        if hostfed is not None:
+            res["facade_hostfed"] = hostfed
         if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cfg, w, h)
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Small fixed workload for rocprofv3: N encode + N decode launches over 20 resident synthetic 4K frames
-(distinct batch per launch).  Prints nothing but a one-line summary; timing comes from the profiler."""
+"""tools/prof_driver.py [n workload width height frames] -- small fixed workload for rocprofv3: N encode + N decode launches
+over `frames` resident synthetic frames each (distinct batch per launch; default 20 x 3840x2160), then the traffic-only probes
+of both directions.  Prints nothing but a one-line summary; timing and counters come from the profiler."""
 import os
 import sys
 
@@ -18,7 +19,9 @@ def main():
             "pq10_ycbcr": (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01, 20.0),
             "log12_luv": (L.PTF_LOG, 12, L.CS_LUV, 8, 1e4, 0.005, 1.0)}
     ptf, bits, cs, bitsC, mx, mn, sc = cfgs[wl]
-    w, h, B = 3840, 2160, 20
+    w = int(sys.argv[3]) if len(sys.argv) > 3 else 3840
+    h = int(sys.argv[4]) if len(sys.argv) > 4 else 2160
+    B = int(sys.argv[5]) if len(sys.argv) > 5 else 20
     n3 = 3 * w * h
     dev = torch.device("cuda:0")
     _, hs, st, _ = L.plane_geometry(w, h, 2)
