@@ -106,12 +106,15 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
         if (c->band_kern[i]) (void)hipEventDestroy(c->band_kern[i]);
     }
     (void)hipFree(c->d_band_stats);
+    auto drop_stage = [](lumahip_ctx::Stage *st) {
+        if (st->ev) (void)hipEventSynchronize(st->ev);
+        if (st->h) (void)hipHostFree(st->h);
+        if (st->ev) (void)hipEventDestroy(st->ev);
+    };
     for (int i = 0; i < lumahip_ctx::N_STAGE; i++)
-        for (auto *st : {&c->stage_up[i], &c->stage_dn[i]}) {
-            if (st->ev) (void)hipEventSynchronize(st->ev);
-            if (st->h) (void)hipHostFree(st->h);
-            if (st->ev) (void)hipEventDestroy(st->ev);
-        }
+        drop_stage(&c->stage_up[i]);
+    for (int i = 0; i < lumahip_ctx::N_STAGE_DN; i++)
+        drop_stage(&c->stage_dn[i]);
     if (c->h_small) (void)hipHostFree(c->h_small);
     lumahip_copy_pool_destroy(c->copy_pool);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);

@@ -158,19 +158,43 @@ static bool host_range_is_pinned(const void *p, size_t bytes)
     return true;
 }
 
-static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
+static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st)
 {
     if (!st.h) {
         HIPCHK(c, hipHostMalloc((void **)&st.h, XFER_CHUNK, hipHostMallocDefault));
         HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
     }
+    return LUMAHIP_OK;
+}
+
+// an upload chunk is free again once the DMA that read it has completed
+static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
+{
+    if (int rc = stage_alloc(c, st))
+        return rc;
     if (st.pending) {
         HIPCHK(c, hipEventSynchronize(st.ev));
         st.pending = false;
-        if (st.out) {   // a device -> host chunk: its DMA has landed, hand the bytes to the caller's memory
-            staged_copy(c, st.out, st.out_pitch, st.h, st.chunk_pitch, st.width, st.rows);
-            st.out = nullptr;
-        }
+    }
+    return LUMAHIP_OK;
+}
+
+// A download chunk is free again once its DMA has landed AND its bytes have been copied out to the caller's pageable
+// memory; the copy happens here, i.e. lazily, when the ring comes round to the chunk again or when a call drains what is
+// still in flight (d2h_flush).  The calling thread therefore never waits for a download it has only just queued: it goes
+// on staging the next upload, which is what keeps the copy engine busy in the batched entry points (pageable frames:
+// 3.1 -> 4.1 Gpixel/s once the fetch of frame i-1 stopped blocking the staging of frame i+1).  A context-owned thread that
+// empties the chunks concurrently was built and measured as well: +2 % on that path, -5 % on the download-heavy decode
+// calls (it copies single-threaded where this thread uses the copy threads), so it was not kept (profiles/r03_hostfed_sweep.txt).
+static int stage_dn_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
+{
+    if (int rc = stage_alloc(c, st))
+        return rc;
+    if (st.pending) {
+        HIPCHK(c, hipEventSynchronize(st.ev));
+        st.pending = false;
+        staged_copy(c, st.out, st.out_pitch, st.h, st.chunk_pitch, st.width, st.rows);
+        st.out = nullptr;
     }
     return LUMAHIP_OK;
 }
@@ -178,10 +202,10 @@ static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
 // every device -> host chunk still in flight: wait for it and copy it out (oldest first)
 static int d2h_flush(lumahip_ctx *c)
 {
-    for (int i = 0; i < lumahip_ctx::N_STAGE; i++) {
-        lumahip_ctx::Stage &st = c->stage_dn[(c->dn_next + i) % lumahip_ctx::N_STAGE];
+    for (int i = 0; i < lumahip_ctx::N_STAGE_DN; i++) {
+        lumahip_ctx::Stage &st = c->stage_dn[(c->dn_next + i) % lumahip_ctx::N_STAGE_DN];
         if (st.h && st.pending)
-            if (int rc = stage_ready(c, st))
+            if (int rc = stage_dn_ready(c, st))
                 return rc;
     }
     return LUMAHIP_OK;
@@ -266,15 +290,14 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
     const size_t total = flat ? width * rows : rows;
     const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;
     for (size_t done = 0; done < total;) {
-        lumahip_ctx::Stage &st = c->stage_dn[c->dn_next++ % lumahip_ctx::N_STAGE];
-        int rc = stage_ready(c, st);   // completes (copies out) the chunk this ring slot carried N_STAGE chunks ago
+        lumahip_ctx::Stage &st = c->stage_dn[c->dn_next++ % lumahip_ctx::N_STAGE_DN];
+        int rc = stage_dn_ready(c, st);   // the chunk this ring slot carried N_STAGE_DN chunks ago has been emptied
         if (rc)
             return rc;
         const size_t n = total - done < per ? total - done : per;
         const size_t bytes = flat ? n : (n - 1) * dp + width;
         HIPCHK(c, hipMemcpyAsync(st.h, (const unsigned char *)src + done * (flat ? 1 : dp), bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(st.ev, s));
-        st.pending = true;
         if (flat) {
             st.out = (unsigned char *)dst + done;
             st.out_pitch = st.chunk_pitch = 0;
@@ -287,6 +310,7 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
             st.width = width;
             st.rows = n;
         }
+        st.pending = true;
         done += n;
     }
     return deferred ? LUMAHIP_OK : d2h_flush(c);
@@ -715,15 +739,16 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         return rc;
     hipStream_t saved = c->stream;
     const size_t pfs[3] = {0, 0, 0};
-    // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched: with pageable planes the fetch
-    // blocks the host (xfer_d2h_2d), and this order keeps the GPU busy with frame i meanwhile.
+    // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched.
     auto fetch = [&](unsigned i) -> int {
         lumahip_ctx::Slot &sl = c->slot[i % 3];
         unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
         (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
         int r = LUMAHIP_OK;
+        // (deferred: pageable planes are copied out of the staging chunks when the ring comes round to them or by the
+        // d2h_flush below -- not here, where it would hold up the staging of the next frame's upload)
         for (int p = 0; p < 3 && r == LUMAHIP_OK; p++)
-            r = xfer_d2h_2d(c, planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h);
+            r = xfer_d2h_2d(c, planes[3 * i + p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h, true);
         if (r)
             return r;
         (void)hipMemcpyAsync(c->h_stats + 3 * (size_t)i, sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
@@ -753,6 +778,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     }
     if (rc == LUMAHIP_OK)
         rc = fetch(nframes - 1);
+    if (int r = d2h_flush(c))   // (also after an error: nothing may stay pending)
+        rc = rc ? rc : r;
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -796,7 +823,7 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
     auto fetch = [&](unsigned i) -> int {  // as in lumahip_encode_frames_host: frame i-1 is fetched after frame i is queued
         lumahip_ctx::Slot &sl = c->slot[i % 3];
         (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
-        int r = xfer_d2h(c, rgb_out[i], sl.d_frame, nfl * sizeof(float), c->s_d2h);
+        int r = xfer_d2h_deferred(c, rgb_out[i], sl.d_frame, nfl * sizeof(float), c->s_d2h);   // (drained lazily, see stage_dn_ready)
         if (r)
             return r;
         (void)hipEventRecord(sl.d2h, c->s_d2h);
@@ -826,6 +853,8 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
     }
     if (rc == LUMAHIP_OK)
         rc = fetch(nframes - 1);
+    if (int r = d2h_flush(c))   // (also after an error: nothing may stay pending)
+        rc = rc ? rc : r;
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));

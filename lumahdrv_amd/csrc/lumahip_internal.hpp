@@ -101,8 +101,9 @@ struct lumahip_ctx {
         unsigned char *out = nullptr;
         size_t out_pitch = 0, chunk_pitch = 0, width = 0, rows = 0;
     };
-    static constexpr int N_STAGE = 4;   // chunks per direction: up to four DMAs queued while the CPU fills / empties the next
-    Stage stage_up[N_STAGE], stage_dn[N_STAGE];
+    static constexpr int N_STAGE = 4;   // upload chunks: up to four DMAs queued while the CPU fills the next
+    static constexpr int N_STAGE_DN = 8;  // download chunks: a 4K frame's planes are five of them
+    Stage stage_up[N_STAGE], stage_dn[N_STAGE_DN];
     unsigned up_next = 0, dn_next = 0;  // ring positions
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
     lumahip_copy_pool *copy_pool = nullptr;

@@ -239,6 +239,32 @@ def test_row_bands_do_not_change_results(oracle_mod, bands, taper):
             c2.close()
 
 
+def test_deferred_downloads_do_not_change_results(oracle_mod):
+    """pageable planes / frames come back through a ring of pinned chunks that is emptied lazily (when the ring comes round,
+    or when the call drains it): batched and single-frame entry points, more frames than pipeline slots, frames larger than
+    the ring of download chunks, both directions."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    c = L.Context(0)
+    c.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11))
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    for (w, h, n, profile) in ((2562, 1442, 7, 2), (1280, 720, 11, 3), (3840, 2160, 4, 2)):
+        frames = [o.synth_frame(w, h, 5, i) for i in range(n)]
+        got, gst, _ = c.encode_frames(frames, 1.0, profile)
+        exp = [orc.encode(f.copy(), 1.0, profile, threads=8) for f in frames]
+        st = exp[0][1]
+        assert tuple(gst) == tuple(st)
+        for i in range(n):
+            assert all(np.array_equal(a, b) for a, b in zip(got[i], exp[i][0])), (w, h, i)
+        dec = c.decode_frames([e[0] for e in exp], st, w, h, 1.0, profile)
+        for i in range(n):
+            assert np.array_equal(dec[i].view(np.uint32), orc.decode(exp[i][0], st, w, h, 1.0, profile, threads=8).view(np.uint32)), (w, h, i)
+        one, st1, _ = c.encode_frame(frames[-1], 1.0, profile)
+        assert all(np.array_equal(a, b) for a, b in zip(one, exp[-1][0]))
+        assert np.array_equal(c.decode_frame(one, st1, w, h, 1.0, profile).view(np.uint32), dec[-1].view(np.uint32))
+    c.close()
+
+
 def _build_cpp(tmp, name):
     exe = os.path.join(tmp, name)
     lib = os.path.join(ROOT, "lumahdrv_amd", "lib")

@@ -88,6 +88,27 @@ int main(int argc, char **argv)
             throw LumaException(lumahip_last_error(ctx));
         const double batch = n * px / (now() - t0) / 1e6;
 
+        // the same batched entry point on PAGEABLE frames and planes (what LumaBatchEncoder gets from plain LumaFrames)
+        std::vector<std::vector<float>> pfr(4);
+        std::vector<std::vector<unsigned char>> ppl(3 * 4);
+        for (int k = 0; k < 4; k++) {
+            pfr[k].assign(fr[k]->buffer, fr[k]->buffer + fr[k]->pixelCount());
+            for (int p = 0; p < 3; p++)
+                ppl[3 * k + p].assign(psz[p] + 4096, 0);
+        }
+        std::vector<const float *> prgb(n);
+        std::vector<unsigned char *> pplp(3 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            prgb[i] = pfr[i % 4].data();
+            for (int p = 0; p < 3; p++)
+                pplp[3 * (size_t)i + p] = ppl[3 * (i % 4) + p].data();
+        }
+        (void)lumahip_encode_frames_host(ctx, prgb.data(), 4, w, h, prm.preScaling, (int)prm.profile, pplp.data(), st, nullptr);
+        t0 = now();
+        if (lumahip_encode_frames_host(ctx, prgb.data(), n, w, h, prm.preScaling, (int)prm.profile, pplp.data(), st, nullptr) != LUMAHIP_OK)
+            throw LumaException(lumahip_last_error(ctx));
+        const double batch_pageable = n * px / (now() - t0) / 1e6;
+
         // decode into a pageable frame (what LumaDecoder::decode hands back)
         std::vector<float> out((size_t)3 * w * h);
         const unsigned char *cpl[3] = {im.planes[0], im.planes[1], im.planes[2]};
@@ -97,14 +118,29 @@ int main(int argc, char **argv)
             if (lumahip_decode_frame_host(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, out.data()) != LUMAHIP_OK)
                 throw LumaException(lumahip_last_error(ctx));
         const double dec = n * px / (now() - t0) / 1e6;
+        // batched decode into pageable frames (4 distinct outputs)
+        std::vector<std::vector<float>> outs(4, std::vector<float>((size_t)3 * w * h));
+        std::vector<const unsigned char *> dpl(3 * (size_t)n);
+        std::vector<float *> dout(n);
+        for (int i = 0; i < n; i++) {
+            dout[i] = outs[i % 4].data();
+            for (int p = 0; p < 3; p++)
+                dpl[3 * (size_t)i + p] = ppl[3 * (i % 4) + p].data();
+        }
+        (void)lumahip_decode_frames_host(ctx, dpl.data(), st, 4, w, h, (int)prm.profile, prm.preScaling, dout.data());
+        t0 = now();
+        if (lumahip_decode_frames_host(ctx, dpl.data(), st, n, w, h, (int)prm.profile, prm.preScaling, dout.data()) != LUMAHIP_OK)
+            throw LumaException(lumahip_last_error(ctx));
+        const double dec_batch = n * px / (now() - t0) / 1e6;
         for (auto &f : fr)
             (void)lumahip_host_unregister(ctx, f->buffer);
         for (auto &v : pl)
             (void)lumahip_host_unregister(ctx, v.data());
         std::printf("{\"width\": %u, \"height\": %u, \"frames\": %d, \"unit\": \"Mpixels/s\", "
                     "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_encode_registered_frame\": %.1f, "
-                    "\"lumahip_encode_frames_host_pinned\": %.1f, \"decode_frame_host_pageable\": %.1f}\n",
-                    w, h, n, pageable, registered, batch, dec);
+                    "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
+                    "\"decode_frame_host_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
+                    w, h, n, pageable, registered, batch, batch_pageable, dec, dec_batch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;
