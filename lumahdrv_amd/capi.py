@@ -65,8 +65,9 @@ def build_library(force: bool = False, nofastdiv: bool = False) -> str:
     return os.path.join(HERE, "lib", "liblumahip.so")
 
 
-KERNEL_SOURCES = ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_internal.hpp", "lumahip_core.hip",
-                  "lumahip_encode.hip", "lumahip_decode.hip", "lumahip_misc.hip", "lut_index.cpp", "flags.mk")
+# device code + launch geometry + compiler flags (NOT the host plumbing: lumahip_core / _host / _pool / _multi, lumahip_internal.hpp)
+KERNEL_SOURCES = ("luma_device.hpp", "luma_kernels.hpp", "pow_glibc.hpp", "lumahip_launch.hip", "lumahip_encode.hip",
+                  "lumahip_decode.hip", "lumahip_misc.hip", "lut_index.cpp", "lut_index.hpp", "flags.mk")
 
 
 def kernel_source_sha() -> str:

@@ -1,11 +1,13 @@
 // lumahip_internal.hpp -- what the translation units behind include/lumahip.h share: the context, error helpers,
 // launch-geometry rules and the device-side implementations the host entry points call.  Not installed, not part of the ABI.
 //
-//   lumahip_core.hip    context life cycle, quantizer upload, launch-geometry rules, memory helpers       (no kernels)
+//   lumahip_core.hip    context life cycle, quantizer upload, layout checks, memory helpers               (no kernels)
+//   lumahip_launch.hip  launch geometry: LDS bytes, threads per workgroup, persistent workgroups per CU   (no kernels)
 //   lumahip_encode.hip  every k_encode / encode-side instantiation and its dispatch
 //   lumahip_decode.hip  every k_decode instantiation and its dispatch
 //   lumahip_misc.hip    stand-alone transform, synthetic frames, the reference's mean luminance, probes, timing helper
 //   lumahip_host.hip    the _host entry points: staging, host <-> device transfers, the 3-slot pipeline   (no kernels)
+//   lumahip_pool.hip    the HBM chunk pool;  lumahip_multi.hip  many GPUs in one process                  (no kernels)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -168,14 +170,15 @@ struct DisplayParams {
     int do_tmo = 0, ldr_sim = 0;
 };
 
+// ---- lumahip_launch.hip
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false);   // ycode: the composite-record encode kernels
+int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false);
 // ---- lumahip_core.hip
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
-size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false);   // ycode: the composite-record encode kernels
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
-int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
-int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false);
 hipStream_t launch_stream(lumahip_ctx *c);   // the context's stream, or the next lane of an unordered section
 void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes);
 // rgb: the three colour-plane base pointers of the float frames (nullptr: no float frames in this call)

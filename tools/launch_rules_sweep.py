@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/launch_rules_sweep.py [--quick] -- are the launch-geometry rules of grid_for / block_threads_for
-(lumahdrv_amd/csrc/lumahip_core.hip) right away from the shape they were found on (20 x 3840x2160)?
+(lumahdrv_amd/csrc/lumahip_launch.hip) right away from the shape they were found on (20 x 3840x2160)?
 
 For {1280x720, 1920x1080, 3840x2160, 7680x4320} x {1, 2, 4, 8, 20, 50 frames per launch} x {PQ-11 Lu'v', HDR10 YCbCr} x
 {encode, decode}: the median kernel time of isolated launches (hipEvent pair around ONE launch, distinct device-resident
