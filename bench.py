@@ -82,6 +82,7 @@ def parse():
                          "groups (lumahip_decode_frames_device_planar); packed: the LumaFrame layout always")
     ap.add_argument("--no-facade-hostfed", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
+    ap.add_argument("--no-placement-off", action="store_true", help="skip the value_placement_off leg (the same kernels on plain allocations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
     ap.add_argument("--placement", default="auto", choices=["auto", "off"],
@@ -806,7 +807,7 @@ def main():
         if rank == 0:
             res["roofline"] = r["roofline"]
             res["decode_roofline"] = r["decode_roofline"]
-        if pool is not None and args.workload == "pq11_luv":
+        if pool is not None and args.workload == "pq11_luv" and not args.no_placement_off:
             # the same kernels on plainly allocated buffers (a 200-frame resident stream, 20 GB >> the 256 MB MALL):
             # what a caller that does not place its buffers gets
             ro, _ = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha, None,

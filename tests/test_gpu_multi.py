@@ -92,6 +92,18 @@ def test_bench_contract_single_gpu():
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
     assert rf["traffic"] is None or abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1) < 0.05
+    # round 3: decode has its own roofline block (own traffic-only probe), the ordered figures sit beside the overlapped ones,
+    # the plain-allocation rate beside the placed one, and the drop-in call on host frames is part of the line
+    dr = r["decode_roofline"]
+    assert dr["bound"] == "hbm" and 0 < dr["frac"] < 1 and dr["traffic_only_ms"] > 0 and dr["kernel_ms"] > 0
+    assert dr["traffic"] is None or abs(dr["traffic"] / dr["algorithmic_bytes_per_launch"] - 1) < 0.05
+    assert rf["kernel_ms_ordered"] > 0 and r["value_ordered"] > 0 and r["lanes"] == 2
+    assert r["ms_per_step_over_ranks"]["min"] <= r["ms_per_step_over_ranks"]["max"]
+    if r["placement"].get("grouped"):
+        assert r["value_placement_off"] > 0
+    hf = r["facade_hostfed"]
+    assert "error" not in hf, hf
+    assert hf["LumaEncoder_encode_pageable_frame"] > 100 and hf["lumahip_encode_frames_host_pageable"] > 100 and hf["runs"] == 3
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_$WL
 mkdir -p $OUT
 P="rocprofv3 --kernel-trace --output-format csv"
-BARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-other-workloads --no-facade-hostfed --min-seconds 0.3 --workload $WL --width $W --height $H --frames-per-step $B"
+BARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-other-workloads --no-facade-hostfed --no-placement-off --min-seconds 0.3 --workload $WL --width $W --height $H --frames-per-step $B"
 echo "{\"width\": $W, \"height\": $H, \"frames\": $B}" > $OUT/shape.json
 $P --stats -d $OUT/stats -o bench -- python bench.py $BARGS > $OUT/bench_under_rocprof.log 2>&1
 python bench.py $BARGS > $OUT/bench_plain.log 2>&1

@@ -206,8 +206,27 @@ def main():
                              drf.get("kernel_ms"), drf.get("kernel_ms_ordered"))]
             except Exception:
                 pass
-        lines += ["", "(The profiler serialises part of the dispatch of concurrent queues, so the overlapped span per launch it sees is",
-                  "longer than in the unprofiled run; the ordered figures agree with bench.py's to a fraction of a per cent.)", ""]
+        so = os.path.join(src, "stats_ordered", "bench_kernel_stats.csv")
+        if os.path.exists(so):
+            lines += ["", "`rocprofv3 --stats` of the same command with `--lanes 0` (`%s_%s_kernel_stats_ordered.csv`: every launch alone on" % (tag, wl),
+                      "its stream, so the profiler's average IS the per-launch time):", ""]
+            for r in csv.DictReader(open(so)):
+                if "k_encode<" in r["Name"] or "k_decode<" in r["Name"]:
+                    lines += ["* `%s`: %s calls, average %.1f us (min %.1f, max %.1f)"
+                              % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                 float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3)]
+            try:
+                line = [l for l in open(os.path.join(src, "bench_ordered_under_rocprof.log")).read().splitlines() if l.startswith('{"metric"')][-1]
+                j = json.loads(line)
+                drf = j.get("decode_roofline", {})
+                drf = drf.get("hbm", drf)
+                lines += ["* bench.py's own hipEvent figures in that run: encode kernel_ms %.4f, decode kernel_ms %s"
+                          % (j["roofline"]["kernel_ms"], drf.get("kernel_ms"))]
+            except Exception:
+                pass
+        lines += ["", "(In the default capture the trace's span per launch of the overlapped runs is not the hipEvent window of the same run:",
+                  "start timestamps of concurrently queued dispatches are taken when the packet is processed.  The ordered figures agree",
+                  "with bench.py's to a fraction of a per cent and are the ones to cross-check `kernel_ms_ordered` with.)", ""]
     lines += ["## roofline.traffic", "",
               "encode HBM bytes per launch = %.5g B; algorithmic = 15 B x %d px = %.5g B (ratio %.4f)"
               % (traffic["encode"], px, 15.0 * px, traffic["encode"] / (15.0 * px)),
