@@ -96,6 +96,18 @@ static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp, bool 
 
 namespace lhost {
 
+// true when no colour plane of the batch starts inside another one's extent: R, G and B are three buffers, not three
+// sections of packed LumaFrames
+static bool planes_are_separate_buffers(float *const rgb[3], size_t frame_stride, unsigned nframes, unsigned w, unsigned h)
+{
+    const size_t extent = ((size_t)(nframes - 1) * frame_stride + (size_t)w * h) * sizeof(float);
+    auto apart = [&](const float *p, const float *q) {
+        const uintptr_t x = (uintptr_t)p, y = (uintptr_t)q;
+        return (x > y ? x - y : y - x) >= extent;
+    };
+    return apart(rgb[0], rgb[1]) && apart(rgb[1], rgb[2]) && apart(rgb[0], rgb[2]);
+}
+
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                 unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
                 const DisplayParams &dp, int cs_eff)
@@ -158,7 +170,13 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr, yt);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles, 1, sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr, cs_eff == CS_YCBCR);
+    // few_writers: the 4:2:0 16-bit kernels of the HBM-bound colour spaces (12 of 15 bytes per pixel are writes); 2 when the three
+    // colour planes of the batch are separate buffers (no plane starts inside another plane's extent over the batch) -- the layout
+    // a caller uses to spread the three write streams over the HBM region groups (lumahip_decode_frames_device_planar)
+    int few_writers = (sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr) ? 1 : 0;
+    if (few_writers && have_rgb && planes_are_separate_buffers(rgb, frame_stride, nframes, w, h))
+        few_writers = 2;
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, few_writers, cs_eff == CS_YCBCR);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, launch_stream(c), a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
@@ -289,7 +307,7 @@ extern "C" int lumahip_probe_decode_traffic_device(lumahip_ctx *c, const unsigne
         a.stride[p] = stride[p];
         a.src_frame_stride[p] = pfs[p];
     }
-    const int grid = grid_for(c, threads, a.g.totalTiles, 1, true, false);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 1, planes_are_separate_buffers(rgb_planes, frame_stride, nframes, w, h) ? 2 : 1, false);
     EventPair ev;
     HIPCHK(c, ev.create());
     HIPCHK(c, hipEventRecord(ev.e0, c->stream));

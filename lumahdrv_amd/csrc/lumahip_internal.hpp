@@ -173,7 +173,7 @@ struct DisplayParams {
 // ---- lumahip_launch.hip
 size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false);   // ycode: the composite-record encode kernels
 int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
-int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers = false, bool ycbcr = false);
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers = 0, bool ycbcr = false);   // few_writers: 0 no, 1 yes, 2 yes with the colour planes in separate buffers
 // ---- lumahip_core.hip
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS

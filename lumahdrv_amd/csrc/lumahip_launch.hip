@@ -58,7 +58,7 @@ int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves)
 // {1, 2, 4, 8, 20, 50 frames} x {Lu'v', YCbCr} x {encode, decode} with every setting interleaved in one process
 // (tools/launch_rules_sweep.py, profiles/r03_launch_rules.txt: before / after tables).  lumahip_tune "grid_enc" / "grid_dec"
 // (absolute) and "blocks_per_cu" (per CU, both directions) are measurement overrides.
-int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool few_writers, bool ycbcr)
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers, bool ycbcr)
 {
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
     const bool rule = c->blocks_per_cu == 0;
@@ -71,6 +71,13 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, bool f
         if (total_tiles >= 60000)
             per_cu = 5;
         else if (total_tiles >= 6000)
+            per_cu = 6;
+        // ... unless the three colour planes are separate buffers (few_writers == 2: R, G, B spread over the HBM region
+        // groups): then 6 per CU stays best on long launches too -- 20 x 4K, ordered: 0.417 ms against 0.436 with 5 and 0.432 with 8
+        // (and against 0.454 / 0.470 / 0.482 for the packed layout; profiles/r03_striped_spread.txt).  That table also explains
+        // round 2's "+11 % on one box, +1.2 % on another" for the striped output: the first figure was taken at 8 per CU, before
+        // the rule above existed (packed 0.482 -> striped 0.432), the second after it (0.454 -> 0.436, +4 %).
+        if (few_writers == 2 && total_tiles >= 6000)
             per_cu = 6;
     }
     // The encode kernels with 256-thread workgroups (tables up to 32 KiB; not YCbCr, which is VALU-bound and wants the
