@@ -27,6 +27,11 @@ BATCHES = (1, 2, 4, 8, 20, 50)
 
 def main():
     quick = "--quick" in sys.argv
+    # --profile N: the VP9 profile (plane layout) swept, default 2 = 4:2:0 16-bit; --small: 1080p and 4K, 1 / 4 / 20 frames only
+    profile = int(sys.argv[sys.argv.index("--profile") + 1]) if "--profile" in sys.argv else 2
+    sizes = SIZES[1:3] if "--small" in sys.argv else SIZES
+    batches = (1, 4, 20) if "--small" in sys.argv else BATCHES
+    print("VP9 profile %d" % profile)
     dev = torch.device("cuda:0")
     worst = []
     for wl, (ptf, bits, cs, bitsC, mx, mn, sc) in WORKLOADS.items():
@@ -41,10 +46,10 @@ def main():
         for direction in (0, 1):
             print("== %s %s: median us per launch; rule | best fixed workgroups-per-CU | rule's loss ==" % (wl, "encode" if direction == 0 else "decode"),
                   flush=True)
-            for (w, h) in SIZES:
-                for B in BATCHES:
+            for (w, h) in sizes:
+                for B in batches:
                     n3 = 3 * w * h
-                    _, hs, st, _ = L.plane_geometry(w, h, 2)
+                    _, hs, st, _ = L.plane_geometry(w, h, profile)
                     psz = [hs[p] * st[p] for p in range(3)]
                     batch_bytes = B * (n3 * 4 + sum(psz))
                     if batch_bytes > 24e9:
@@ -54,7 +59,7 @@ def main():
                     planes = [torch.zeros(nb * B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
                     ctxs[0].synth_frames_device(src.data_ptr(), n3, nb * B, w, h)
                     for b in range(nb):      # planes hold real codes for the decode side
-                        ctxs[0].encode_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, sc, 2,
+                        ctxs[0].encode_frames_device(src.data_ptr() + b * B * n3 * 4, n3, B, w, h, sc, profile,
                                                      [planes[p].data_ptr() + b * B * psz[p] for p in range(3)], st, psz)
                     torch.cuda.synchronize()
                     reps = 2 if quick else max(2, min(6, 72 // nb))
@@ -65,7 +70,7 @@ def main():
                             for k, c in ctxs.items():
                                 bb = (b + i) % nb
                                 i += 1
-                                t = c.time_launches(direction, 1, src.data_ptr() + bb * B * n3 * 4, n3, B, w, h, sc, 2,
+                                t = c.time_launches(direction, 1, src.data_ptr() + bb * B * n3 * 4, n3, B, w, h, sc, profile,
                                                     [planes[p].data_ptr() + bb * B * psz[p] for p in range(3)], st, psz)
                                 if rep > 0:        # first round = warm-up
                                     ms[k].append(t)
