@@ -589,11 +589,20 @@ def run_stream_multi(L, args):
     m.sync()
     steps = max((len(r) + B - 1) // B for r in shards)
 
+    lanes = max(0, args.lanes)
+
     def one_pass():
+        # the steps of a pass are independent batches: every shard runs them inside one unordered section (two lanes)
+        if lanes:
+            for s in range(ns):
+                m.ctx(s).begin_unordered(lanes)
         for k in range(steps):
             counts = [max(0, min(B, len(shards[s]) - k * B)) for s in range(ns)]
             m.encode_frames_device([src[s].data_ptr() + k * B * n3 * 4 for s in range(ns)], n3, counts, w, h, sc, profile,
                                    [[planes[s][p].data_ptr() + k * B * psz[p] for p in range(3)] for s in range(ns)], st, psz)
+        if lanes:
+            for s in range(ns):
+                m.ctx(s).end_unordered()
         m.sync()
 
     one_pass()                                  # warm-up
