@@ -62,3 +62,19 @@ def test_chunk_pool_builds_and_placement_does_not_change_results(oracle_mod):
     ctx.set_stream(None)
     ctx.close()
     assert CHUNK_BYTES == 2 << 30
+
+
+def test_pool_stream_cpp_example():
+    """tools/pool_stream.cpp: a resident stream carved from lumahip_pool_* from plain C++ over the C ABI (no Python, no torch),
+    against the same stream in lumahip_malloc buffers: same bytes, and -- where the box shows region groups -- not slower."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "lumahdrv_amd", "bin", "pool_stream")
+    r = subprocess.run([exe, "6", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["planes_identical"] is True and d["batches"] == 6 and d["pooled_mpix_s"] > 1e5 and d["plain_mpix_s"] > 1e5
+    if d["pool"].get("grouped"):
+        assert d["pooled_mpix_s"] >= 0.97 * d["plain_mpix_s"]
