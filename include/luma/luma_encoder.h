@@ -83,13 +83,26 @@ public:
     // ---- additions ----
     void setSink(LumaPlaneSink *sink) { m_sink = sink; }     // not owned; default: raw plane stream
     void setInPlaceCompat(bool on) { m_inPlaceCompat = on; }
-    const LumaPlanes &getRawFrame() const { return m_rawFrame.image(); }  // the filled Y/U/V planes (m_rawFrame)
+    // Pipelined mode (opt-in, before initialize): encode(frame i+1) uploads and launches frame i+1 and only THEN completes frame i
+    // and hands its planes to the sink -- one frame of latency, finish() delivers the last one.  The tail of a frame (kernel,
+    // download of the planes, copy out of the staging buffers) then runs under the next frame's upload, which a synchronous
+    // call cannot do: pageable 4K LumaFrames 3.2 -> 4 Gpixel/s (PCIe).  `frame` may be reused as soon as encode() returns, as in
+    // the default mode; the sink sees the same planes in the same order.  getRawFrame() / lastMeanLuminance() and the mean
+    // luminance warning refer to the frame most recently DELIVERED.  Not combinable with setInPlaceCompat(true).
+    void setPipelined(bool on) { m_pipelined = on; }
+    bool pipelined() const { return m_pipelined; }
+    const LumaPlanes &getRawFrame() const { return m_delivered ? m_delivered->image() : m_rawFrame.image(); }  // the filled Y/U/V planes
     LumaQuantizer *getQuantizer() { return &m_quant; }
     float lastMeanLuminance() const { return m_lastMean; }
 
 private:
     void warnMean(float avg);
+    bool deliverOldest();          // pipelined mode: complete the oldest frame in flight and hand it to the sink
     LumaPlaneBuffer m_rawFrame;
+    LumaPlaneBuffer m_rawFrame2;   // pipelined mode: the planes of two frames alternate between m_rawFrame and this one
+    const LumaPlaneBuffer *m_delivered;
+    unsigned int m_pushed;
+    bool m_pipelined;
     unsigned int m_frameCount;
     LumaEncoderParams m_params;
     LumaPlaneSink *m_sink;

@@ -154,6 +154,21 @@ int lumahip_encode_frames_host(lumahip_ctx *ctx, const float *const *rgb, unsign
 int lumahip_decode_frames_host(lumahip_ctx *ctx, const unsigned char *const *planes, const int stride[3],
                                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const *rgb_out);
 
+/* Streaming form of lumahip_encode_frames_host for callers that get their frames one at a time -- the reference's loop
+ * `for (...) encoder.encode(&frame)` (lumaenc.cpp:205-243) -- and accept ONE frame of latency: push(frame i+1), then pop(frame i).
+ * A synchronous one-frame call cannot overlap its tail (last kernel, download, copy out of the staging chunks, ~0.5 ms of
+ * 2.6 ms for a pageable 4K frame) with anything; here it runs under the next frame's upload.
+ * push: uploads `rgb` (LumaFrame layout), queues the fused kernel and the download of the planes into `planes` / `stride`, and
+ * returns as soon as `rgb` may be reused; `planes` must stay valid until the frame is popped.  At most two frames in flight
+ * (LUMAHIP_ERR_STATE otherwise), same w / h / profile while a frame is in flight.
+ * pop: completes the OLDEST pushed frame -- its planes are in the caller's memory when it returns; mean_lum (nullable) as in
+ * lumahip_encode_frame_host.  Results are identical to lumahip_encode_frame_host.  The batched entry points refuse to run while
+ * frames are pending; everything else may be called in between. */
+int lumahip_encode_stream_push(lumahip_ctx *ctx, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                               unsigned char *const planes[3], const int stride[3]);
+int lumahip_encode_stream_pop(lumahip_ctx *ctx, float *mean_lum);
+int lumahip_encode_stream_pending(const lumahip_ctx *ctx);   /* frames pushed and not yet popped: 0, 1 or 2 */
+
 /* Replaces LumaEncoder::setChannels(LumaFrame*) on its own (src/luma_encoder.cpp:196-201): quantize + pack a
  * frame that is ALREADY colour-transformed.  And LumaDecoder::getVpxChannels on its own
  * (src/luma_decoder.cpp:205-240): unpack + dequantize without the inverse colour transform. */

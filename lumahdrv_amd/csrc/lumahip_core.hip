@@ -116,6 +116,7 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     for (int i = 0; i < lumahip_ctx::N_STAGE_DN; i++)
         drop_stage(&c->stage_dn[i]);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_es_stats) (void)hipHostFree(c->h_es_stats);
     lumahip_copy_pool_destroy(c->copy_pool);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_kern) (void)hipStreamDestroy(c->s_kern);

@@ -211,6 +211,18 @@ static int d2h_flush(lumahip_ctx *c)
     return LUMAHIP_OK;
 }
 
+// the chunks of pushed frames up to sequence number `seq` (stream entry points; chunks are in issue order, oldest first)
+static int d2h_flush_upto(lumahip_ctx *c, unsigned seq)
+{
+    for (int i = 0; i < lumahip_ctx::N_STAGE_DN; i++) {
+        lumahip_ctx::Stage &st = c->stage_dn[(c->dn_next + i) % lumahip_ctx::N_STAGE_DN];
+        if (st.h && st.pending && (int)(st.tag - seq) <= 0)
+            if (int rc = stage_dn_ready(c, st))
+                return rc;
+    }
+    return LUMAHIP_OK;
+}
+
 // rows x width bytes, host pitch hp, device pitch dp.  Returns once the copies are queued on `s` (the caller's buffer
 // is no longer needed if it was pageable: it has been copied into the staging chunks).
 static int xfer_h2d_2d(lumahip_ctx *c, void *dst, size_t dp, const void *src, size_t hp, size_t width, size_t rows, hipStream_t s)
@@ -310,6 +322,7 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
             st.width = width;
             st.rows = n;
         }
+        st.tag = c->d2h_tag;
         st.pending = true;
         done += n;
     }
@@ -735,6 +748,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
                 return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
     }
     const size_t nfl = (size_t)3 * w * h;
+    if (c->es_head != c->es_tail)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still pending: pop them first");
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
     hipStream_t saved = c->stream;
@@ -796,6 +811,103 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     return rc;
 }
 
+// ---- streaming form of the batched encode: frames arrive one at a time ------------------------------------------------------
+// lumahip_encode_frames_host needs the whole batch in hand.  A caller that gets its frames one by one (the reference's
+// `for (...) encoder.encode(&frame)` loop, lumaenc.cpp:205-243) can still overlap the tail of frame i (kernel, download,
+// copy out of the staging chunks) with the upload of frame i+1 by accepting ONE frame of latency: push(i+1), then pop(i).
+// Same three device slots and three streams as the batched form; at most two frames in flight.
+extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsigned w, unsigned h, float sc, int profile,
+                                          unsigned char *const planes[3], const int stride[3])
+{
+    if (!c || !rgb || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, c->q.cs);
+    if (rc)
+        return rc;
+    if (c->es_head - c->es_tail >= 2)
+        return fail(c, LUMAHIP_ERR_STATE, "two frames are in flight already: lumahip_encode_stream_pop the oldest first");
+    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile))
+        return fail(c, LUMAHIP_ERR_STATE, "frame geometry changed while a frame is in flight: pop it first");
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride too small", p);
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, 1)))   // (reallocates only when nothing is in flight: same geometry otherwise)
+        return rc;
+    if (!c->h_es_stats)
+        HIPCHK(c, hipHostMalloc((void **)&c->h_es_stats, 3 * 3 * sizeof(float), hipHostMallocDefault));
+    const unsigned seq = c->es_head;
+    lumahip_ctx::Slot &sl = c->slot[seq % 3];
+    unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+    const size_t pfs[3] = {0, 0, 0};
+    // the slot's previous occupant (frame seq - 3) was popped long ago; its kernel and downloads are done, but the streams
+    // still have to be told (events of that occupancy)
+    if (seq >= 3) {
+        (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);
+        (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
+    }
+    c->up_ramp = 0;
+    const bool pinned_in = host_range_is_pinned(rgb, nfl * sizeof(float));
+    if ((rc = xfer_h2d(c, sl.d_frame, rgb, nfl * sizeof(float), c->s_h2d)))
+        return rc;
+    (void)hipEventRecord(sl.h2d, c->s_h2d);
+    (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+    hipStream_t saved = c->stream;
+    c->stream = c->s_kern;
+    rc = lumahip_encode_frames_device(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+    c->stream = saved;
+    if (rc)
+        return rc;
+    (void)hipEventRecord(sl.kern, c->s_kern);
+    // the planes come down behind the kernel; pageable ones are emptied out of the staging chunks by the pop (or earlier,
+    // when the ring comes round)
+    (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+    c->d2h_tag = seq;
+    for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++)
+        rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h, true);
+    c->d2h_tag = 0;
+    if (rc)
+        return rc;
+    (void)hipMemcpyAsync(c->h_es_stats + 3 * (seq % 3), sl.d_stats, 3 * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
+    (void)hipEventRecord(sl.d2h, c->s_d2h);
+    if (pinned_in)
+        HIPCHK(c, hipEventSynchronize(sl.h2d));   // the copy engine read the caller's memory directly: it must be done with it
+    c->es_w = w;
+    c->es_h = h;
+    c->es_profile = profile;
+    c->es_sc = sc;
+    c->es_head = seq + 1;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_encode_stream_pop(lumahip_ctx *c, float *mean_lum)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (c->es_head == c->es_tail)
+        return fail(c, LUMAHIP_ERR_STATE, "no frame is in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned seq = c->es_tail;
+    lumahip_ctx::Slot &sl = c->slot[seq % 3];
+    c->es_tail = seq + 1;                        // (popped even if something below fails: nothing may stay half-finished)
+    int rc = d2h_flush_upto(c, seq);
+    HIPCHK(c, hipEventSynchronize(sl.d2h));      // downloads into pinned planes, and the statistics
+    if (rc)
+        return rc;
+    if (mean_lum) {
+        const float *stp = c->h_es_stats + 3 * (seq % 3);
+        *mean_lum = stp[0] / (float)((int)c->es_w * (int)c->es_h);
+        if (mean_needs_reference_sum(*mean_lum, stp[1], c->es_w, c->es_h))   // the slot still holds the frame as it was uploaded
+            return mean_luminance_reference_impl(c, sl.d_frame, c->es_w, c->es_h, c->es_sc, c->q.cs, mean_lum);
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_encode_stream_pending(const lumahip_ctx *c) { return c ? (int)(c->es_head - c->es_tail) : 0; }
+
 extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *const *planes, const int stride[3],
                                           unsigned nframes, unsigned w, unsigned h, int profile, float sc,
                                           float *const *rgb_out)
@@ -816,6 +928,8 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
                 return fail(c, LUMAHIP_ERR_ARG, "frame %u plane %d: null or stride too small", i, p);
     }
     const size_t nfl = (size_t)3 * w * h;
+    if (c->es_head != c->es_tail)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still pending: pop them first");
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
     hipStream_t saved = c->stream;

@@ -102,11 +102,19 @@ struct lumahip_ctx {
         // device -> host only: what to do with the chunk once its DMA has landed (copy it out to the caller's pageable memory)
         unsigned char *out = nullptr;
         size_t out_pitch = 0, chunk_pitch = 0, width = 0, rows = 0;
+        unsigned tag = 0;      // which pushed frame the chunk belongs to (lumahip_encode_stream_push); 0 outside a stream
     };
     static constexpr int N_STAGE = 4;   // upload chunks: up to four DMAs queued while the CPU fills the next
     static constexpr int N_STAGE_DN = 8;  // download chunks: a 4K frame's planes are five of them
     Stage stage_up[N_STAGE], stage_dn[N_STAGE_DN];
     unsigned up_next = 0, dn_next = 0;  // ring positions
+    // frames pushed with lumahip_encode_stream_push and not yet popped: sequence numbers [es_tail, es_head), frame j in slot[j % 3]
+    unsigned es_head = 0, es_tail = 0;
+    unsigned es_w = 0, es_h = 0;
+    int es_profile = 0;
+    float es_sc = 1.0f;
+    float *h_es_stats = nullptr;   // pinned, 3 floats per slot
+    unsigned d2h_tag = 0;          // tag given to download chunks queued now
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
     lumahip_copy_pool *copy_pool = nullptr;
     int copy_threads = 3;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)

@@ -3,7 +3,8 @@
 // H2D of 12 B/pixel + the fused kernel + D2H of the planes, one frame per call, synchronous.  PCIe-bound by construction;
 // bench.py prints these figures as `facade_hostfed` next to (never as) the device-resident `value`.
 //   facade_hostfed [w h frames]          -> one JSON line on stdout
-// Rows: a pageable LumaFrame (plain new float[], what the reference's LumaFrame is), the same frame pinned with
+// Rows: a pageable LumaFrame (plain new float[], what the reference's LumaFrame is), the same loop in the facade's pipelined
+// mode, the same frame pinned with
 // lumahip_host_register, the batched pinned C-ABI entry point (3-slot pipeline), and LumaDecoder-side decode into a
 // pageable frame (lumahip_decode_frame_host, what LumaDecoder::decode calls).
 #include <chrono>
@@ -53,6 +54,23 @@ int main(int argc, char **argv)
         for (int i = 0; i < n; i++)
             enc.encode(fr[i % 4].get());
         const double pageable = n * px / (now() - t0) / 1e6;
+
+        // the same loop with LumaEncoder::setPipelined(true): frame i+1 goes up before frame i is completed (one frame of latency)
+        double pipelined = 0.0;
+        {
+            NullSink psink;
+            LumaEncoder penc;
+            penc.setSink(&psink);
+            penc.setPipelined(true);
+            penc.initialize("null", w, h);
+            penc.encode(fr[0].get());
+            penc.encode(fr[1].get());
+            const double tp = now();
+            for (int i = 0; i < n; i++)
+                penc.encode(fr[i % 4].get());
+            pipelined = n * px / (now() - tp) / 1e6;
+            penc.finish();
+        }
 
         lumahip_ctx *ctx = enc.getQuantizer()->context();
         for (auto &f : fr)
@@ -137,10 +155,11 @@ int main(int argc, char **argv)
         for (auto &v : pl)
             (void)lumahip_host_unregister(ctx, v.data());
         std::printf("{\"width\": %u, \"height\": %u, \"frames\": %d, \"unit\": \"Mpixels/s\", "
-                    "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_encode_registered_frame\": %.1f, "
+                    "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_frame\": %.1f, "
+                    "\"LumaEncoder_encode_registered_frame\": %.1f, "
                     "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
                     "\"decode_frame_host_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
-                    w, h, n, pageable, registered, batch, batch_pageable, dec, dec_batch);
+                    w, h, n, pageable, pipelined, registered, batch, batch_pageable, dec, dec_batch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;

@@ -153,6 +153,10 @@ int main(int argc, char *argv[])
             flush();
             batch.finish();
         } else {
+            // one GPU: the reference's loop as it stands, with the encoder in pipelined mode (frame i+1 is read from disk and
+            // uploaded while frame i is still being finished; the stream written is the same, LUMAENC_PIPELINED=0 switches it off)
+            const char *pipeEnv = std::getenv("LUMAENC_PIPELINED");
+            encoder.setPipelined(!(pipeEnv && std::atoi(pipeEnv) == 0));
             for (unsigned int f = job.first; f <= job.last; f += job.step) {
                 LumaFrame frame;
                 fetch(job, f, frame);
