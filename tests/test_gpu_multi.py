@@ -104,6 +104,7 @@ def test_bench_contract_single_gpu():
     hf = r["facade_hostfed"]
     assert "error" not in hf, hf
     assert hf["LumaEncoder_encode_pageable_frame"] > 100 and hf["lumahip_encode_frames_host_pageable"] > 100 and hf["runs"] == 3
+    assert hf["LumaEncoder_pipelined_encode_pageable_frame"] > 100
 
 
 @pytest.mark.gpu
