@@ -158,11 +158,12 @@ static bool host_range_is_pinned(const void *p, size_t bytes)
     return true;
 }
 
-static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st)
+static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st, size_t bytes = XFER_CHUNK)
 {
     if (!st.h) {
-        HIPCHK(c, hipHostMalloc((void **)&st.h, XFER_CHUNK, hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void **)&st.h, bytes, hipHostMallocDefault));
+        if (!st.ev)
+            HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
     }
     return LUMAHIP_OK;
 }
@@ -188,7 +189,7 @@ static int stage_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
 // calls (it copies single-threaded where this thread uses the copy threads), so it was not kept (profiles/r03_hostfed_sweep.txt).
 static int stage_dn_ready(lumahip_ctx *c, lumahip_ctx::Stage &st)
 {
-    if (int rc = stage_alloc(c, st))
+    if (int rc = stage_alloc(c, st, c->dn_chunk))
         return rc;
     if (st.pending) {
         HIPCHK(c, hipEventSynchronize(st.ev));
@@ -208,6 +209,29 @@ static int d2h_flush(lumahip_ctx *c)
             if (int rc = stage_dn_ready(c, st))
                 return rc;
     }
+    return LUMAHIP_OK;
+}
+
+// The pipelined encode paths queue a whole frame's planes for download and go back to staging the next upload; that only
+// works while the ring of download chunks holds the frame (five chunks of 8 MiB for a 4K frame's 25 MB, eight are there).
+// The planes of an 8K frame are 99.5 MB: thirteen such chunks -- the ring came round to chunks of the SAME frame, the host sat
+// waiting for its kernel, and the pipelined paths were slower than the synchronous one (3.35 against 3.55 Gpixel/s).  So the
+// download chunks grow with the frame (a fifth of the planes, at most 32 MiB each); they are re-allocated only when nothing is
+// in flight.
+static int dn_chunks_for(lumahip_ctx *c, size_t planes_bytes)
+{
+    size_t want = ((planes_bytes / 5 + ((size_t)1 << 20) - 1) >> 20) << 20;
+    want = std::min(std::max(want, XFER_CHUNK), (size_t)32 << 20);
+    if (want <= c->dn_chunk)
+        return LUMAHIP_OK;
+    if (int rc = d2h_flush(c))
+        return rc;
+    for (auto &st : c->stage_dn)
+        if (st.h) {
+            (void)hipHostFree(st.h);
+            st.h = nullptr;   // (the event stays; stage_alloc makes the new buffer on first use)
+        }
+    c->dn_chunk = want;
     return LUMAHIP_OK;
 }
 
@@ -297,10 +321,10 @@ static int xfer_d2h_2d(lumahip_ctx *c, void *dst, size_t hp, const void *src, si
         return LUMAHIP_OK;
     }
     const bool flat = (dp == width && hp == width);
-    if (!flat && dp > XFER_CHUNK)
+    if (!flat && dp > c->dn_chunk)
         return fail(c, LUMAHIP_ERR_ARG, "row pitch %zu exceeds the staging chunk", dp);
     const size_t total = flat ? width * rows : rows;
-    const size_t per = flat ? XFER_CHUNK : XFER_CHUNK / dp;
+    const size_t per = flat ? c->dn_chunk : c->dn_chunk / dp;
     for (size_t done = 0; done < total;) {
         lumahip_ctx::Stage &st = c->stage_dn[c->dn_next++ % lumahip_ctx::N_STAGE_DN];
         int rc = stage_dn_ready(c, st);   // the chunk this ring slot carried N_STAGE_DN chunks ago has been emptied
@@ -752,6 +776,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still pending: pop them first");
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
+    if ((rc = dn_chunks_for(c, L.total)))
+        return rc;
     hipStream_t saved = c->stream;
     const size_t pfs[3] = {0, 0, 0};
     // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched.
@@ -836,6 +862,8 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
             return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride too small", p);
     const size_t nfl = (size_t)3 * w * h;
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, 1)))   // (reallocates only when nothing is in flight: same geometry otherwise)
+        return rc;
+    if (c->es_head == c->es_tail && (rc = dn_chunks_for(c, L.total)))
         return rc;
     if (!c->h_es_stats)
         HIPCHK(c, hipHostMalloc((void **)&c->h_es_stats, 3 * 3 * sizeof(float), hipHostMallocDefault));

@@ -108,6 +108,7 @@ struct lumahip_ctx {
     static constexpr int N_STAGE_DN = 8;  // download chunks: a 4K frame's planes are five of them
     Stage stage_up[N_STAGE], stage_dn[N_STAGE_DN];
     unsigned up_next = 0, dn_next = 0;  // ring positions
+    size_t dn_chunk = (size_t)8 << 20;  // bytes per download chunk (grows with the frames of the pipelined encode paths)
     // frames pushed with lumahip_encode_stream_push and not yet popped: sequence numbers [es_tail, es_head), frame j in slot[j % 3]
     unsigned es_head = 0, es_tail = 0;
     unsigned es_w = 0, es_h = 0;
