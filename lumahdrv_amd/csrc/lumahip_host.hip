@@ -445,7 +445,9 @@ static int pipe_streams(lumahip_ctx *c);
 static int band_plan(const lumahip_ctx *c, unsigned w, unsigned h, unsigned r0[lumahip_ctx::MAX_BANDS + 1])
 {
     int nb = c->host_bands;
-    if ((size_t)w * h < (size_t)1 << 20 || nb < 2)      // small frames: latency, not bandwidth
+    // small frames are latency, not bandwidth: up to 1920x1080 one piece is as fast or faster (registered frames +10 %, pageable
+    // +-0; profiles/r03_hostfed_sweep.txt), from 2560x1440 on the bands win (pageable +12 %)
+    if ((size_t)w * h < (size_t)3 << 20 || nb < 2)
         nb = 1;
     const double q = c->band_taper / 100.0;
     double wsum = 0.0, wk = 1.0;
