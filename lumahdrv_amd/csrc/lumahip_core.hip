@@ -469,6 +469,8 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
         return fail(c, LUMAHIP_ERR_ARG, "LUT must hold 2^bitdepth = %zu floats (got %zu)", (size_t)1 << bitdepth, n);
     if (ptf < 0 || ptf > 4)
         return fail(c, LUMAHIP_ERR_ARG, "unknown transfer function %d", ptf);
+    if (c->es_head != c->es_tail)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still in flight: pop them before changing the quantizer");
     // an unknown colour space is accepted here, as in the reference (setQuantizer stores it blindly,
     // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
     HIPCHK(c, hipSetDevice(c->device));

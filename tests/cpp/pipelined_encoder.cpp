@@ -116,6 +116,11 @@ int main(int argc, char **argv)
         const float *one[1] = {fr.buffer};
         unsigned char *pl3[3] = {pb[2].image().planes[0], pb[2].image().planes[1], pb[2].image().planes[2]};
         ok = ok && lumahip_encode_frames_host(ctx, one, 1, w, h, 1.0f, 2, pl3, pb[2].image().stride, NULL) == LUMAHIP_ERR_STATE;   // batched form
+        {   // the quantizer cannot be replaced under frames in flight
+            std::vector<float> lut(2048);
+            ok = ok && lumahip_build_lut(LUMAHIP_PTF_PQ, 11, 1e4f, 0.005f, lut.data(), lut.size()) == LUMAHIP_OK;
+            ok = ok && lumahip_set_quantizer(ctx, LUMAHIP_PTF_PQ, 11, LUMAHIP_CS_LUV, 8, 1e4f, 0.005f, lut.data(), lut.size()) == LUMAHIP_ERR_STATE;
+        }
         // a synchronous single-frame call in between is allowed and must not disturb the frames in flight
         ok = ok && lumahip_encode_frame_host(ctx, fr.buffer, w, h, 1.0f, 2, pb[2].image().planes, pb[2].image().stride, &m, NULL) == LUMAHIP_OK;
         ok = ok && lumahip_encode_stream_pop(ctx, &m) == LUMAHIP_OK && lumahip_encode_stream_pop(ctx, &m) == LUMAHIP_OK;

@@ -222,7 +222,7 @@ def test_row_bands_do_not_change_results(oracle_mod, bands, taper):
         c.tune("band_taper", taper)
         c.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
         orc = o.Oracle(*cfg)
-        for (w, h) in ((1922, 1082), (2048, 514), (1026, 1100)):     # >= 2^20 pixels: banded; 514 rows: fewer bands than asked
+        for (w, h) in ((2562, 1442), (6400, 514), (1538, 2102)):     # >= 3 * 2^20 pixels: banded; 514 rows: fewer bands than asked
             f = o.synth_frame(w, h, 11, bands)
             planes, st, mean = c.encode_frame(f, sc, 2)
             e, st2, emean = orc.encode(f.copy(), sc, 2)
