@@ -75,6 +75,13 @@ public:
 
     // ---- additions ----
     void setSource(LumaPlaneSource *src) { m_source = src; }  // not owned; default: raw plane stream
+    // Pipelined mode (opt-in): decode() reads and uploads the planes of frame i+1 and queues its kernel BEFORE it completes
+    // frame i and returns it, so the download of a frame (12 B/pixel, the heavy direction here) runs under the next frame's
+    // read, upload and kernel.  Same frames in the same order; the returned frame is valid until the next decode(), as always.
+    // getFrame() is then not meaningful between calls, run() / getBuffer() refer to the frame read AHEAD, and seekToTime()
+    // first drops what is in flight.
+    void setPipelined(bool on) { m_pipelined = on; }
+    bool pipelined() const { return m_pipelined; }
 
 private:
     LumaDecoderParams m_params;
@@ -84,6 +91,11 @@ private:
     LumaPlaneSource *m_source;
     LumaRawStreamReader m_rawReader;
     float m_time;
+    bool pushNext();               // pipelined mode: read the next frame's planes and start it; false at the end of the stream
+    void dropInFlight();
+    LumaFrame m_frame2;            // pipelined mode: decoded frames alternate between m_frame and this one
+    unsigned int m_pushed;
+    bool m_pipelined;
 };
 
 #endif

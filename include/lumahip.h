@@ -168,6 +168,14 @@ int lumahip_encode_stream_push(lumahip_ctx *ctx, const float *rgb, unsigned w, u
                                unsigned char *const planes[3], const int stride[3]);
 int lumahip_encode_stream_pop(lumahip_ctx *ctx, float *mean_lum);
 int lumahip_encode_stream_pending(const lumahip_ctx *ctx);   /* frames pushed and not yet popped: 0, 1 or 2 */
+/* The decode counterpart, for the loop `while ((frame = decoder.decode()))` (lumadec.cpp:112-160): push uploads the planes
+ * (they may be reused when it returns), queues the fused kernel and the download into `rgb_out` (LumaFrame layout), which must
+ * stay valid until the frame is popped; pop completes the oldest pushed frame.  Same rules as above; encode and decode frames
+ * cannot be in flight at the same time on one context. */
+int lumahip_decode_stream_push(lumahip_ctx *ctx, const unsigned char *const planes[3], const int stride[3], unsigned w, unsigned h,
+                               int profile, float sc, float *rgb_out);
+int lumahip_decode_stream_pop(lumahip_ctx *ctx);
+int lumahip_decode_stream_pending(const lumahip_ctx *ctx);
 
 /* Replaces LumaEncoder::setChannels(LumaFrame*) on its own (src/luma_encoder.cpp:196-201): quantize + pack a
  * frame that is ALREADY colour-transformed.  And LumaDecoder::getVpxChannels on its own

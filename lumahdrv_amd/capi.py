@@ -22,6 +22,7 @@ SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
     "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
+    "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device", "lumahip_mean_luminance_reference_device",

@@ -7,7 +7,7 @@
 #include "../../../include/lumahip.h"
 
 LumaDecoder::LumaDecoder(const char *inputFile, bool verbose)
-    : m_vpxFrame(NULL), m_firstFrame(false), m_source(NULL), m_time(0.0f)
+    : m_vpxFrame(NULL), m_firstFrame(false), m_source(NULL), m_time(0.0f), m_pushed(0), m_pipelined(false)
 {
     m_planePtrs[0] = m_planePtrs[1] = m_planePtrs[2] = NULL;
     if (inputFile != NULL) {
@@ -16,7 +16,52 @@ LumaDecoder::LumaDecoder(const char *inputFile, bool verbose)
     }
 }
 
-LumaDecoder::~LumaDecoder() {}
+LumaDecoder::~LumaDecoder()
+{
+    // frames still in flight are being written into m_frame / m_frame2: complete them before the buffers go away
+    if (m_quant.context())
+        dropInFlight();
+}
+
+void LumaDecoder::dropInFlight()
+{
+    while (lumahip_decode_stream_pending(m_quant.context()) > 0)
+        if (lumahip_decode_stream_pop(m_quant.context()) != LUMAHIP_OK)
+            break;
+}
+
+static void allocateFrame(LumaFrame &f, unsigned int w, unsigned int h)
+{
+    if (f.width)
+        return;
+    f.width = w;
+    f.height = h;
+    f.channels = 3;
+    bool ok = false;
+    try {
+        ok = f.init();
+    } catch (const std::exception &) {   // std::bad_alloc: callers catch LumaException, as the reference's apps do
+    }
+    if (!ok) {
+        f.width = f.height = 0;
+        throw LumaException("Cannot allocate memory for the decoded frame");
+    }
+}
+
+bool LumaDecoder::pushNext()
+{
+    if (!run())
+        return false;
+    LumaFrame &dst = (m_pushed & 1) ? m_frame2 : m_frame;
+    allocateFrame(dst, m_vpxFrame->d_w, m_vpxFrame->d_h);
+    const unsigned char *pl[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
+    const int rc = lumahip_decode_stream_push(m_quant.context(), pl, m_vpxFrame->stride, m_vpxFrame->d_w, m_vpxFrame->d_h,
+                                              m_vpxFrame->profile(), m_params.preScaling, dst.buffer);
+    if (rc != LUMAHIP_OK)
+        throw LumaException(lumahip_last_error(m_quant.context()));
+    m_pushed++;
+    return true;
+}
 
 bool LumaDecoder::initialize(const char *inputFile, bool verbose)
 {
@@ -111,22 +156,21 @@ bool LumaDecoder::run()
 
 LumaFrame *LumaDecoder::decode()
 {
+    if (m_pipelined) {
+        // keep two frames started, complete and return the older one (luma_decoder.h: setPipelined)
+        while (lumahip_decode_stream_pending(m_quant.context()) < 2 && pushNext()) {
+        }
+        const int pending = lumahip_decode_stream_pending(m_quant.context());
+        if (pending <= 0)
+            return NULL;
+        const unsigned int seq = m_pushed - (unsigned int)pending;
+        if (lumahip_decode_stream_pop(m_quant.context()) != LUMAHIP_OK)
+            throw LumaException(lumahip_last_error(m_quant.context()));
+        return (seq & 1) ? &m_frame2 : &m_frame;
+    }
     if (!run())
         return NULL;
-    if (!m_frame.width) {
-        m_frame.width = m_vpxFrame->d_w;
-        m_frame.height = m_vpxFrame->d_h;
-        m_frame.channels = 3;
-        bool ok = false;
-        try {
-            ok = m_frame.init();
-        } catch (const std::exception &) {   // std::bad_alloc: callers catch LumaException, as the reference's apps do
-        }
-        if (!ok) {
-            m_frame.width = m_frame.height = 0;
-            throw LumaException("Cannot allocate memory for the decoded frame");
-        }
-    }
+    allocateFrame(m_frame, m_vpxFrame->d_w, m_vpxFrame->d_h);
     const unsigned char *pl[3] = {m_vpxFrame->planes[0], m_vpxFrame->planes[1], m_vpxFrame->planes[2]};
     const int rc = lumahip_decode_frame_host(m_quant.context(), pl, m_vpxFrame->stride, m_vpxFrame->d_w, m_vpxFrame->d_h,
                                              m_vpxFrame->profile(), m_params.preScaling, m_frame.buffer);
@@ -138,6 +182,7 @@ LumaFrame *LumaDecoder::decode()
 void LumaDecoder::seekToTime(float tm, bool absolute)
 {
     // the raw plane stream is constant-rate: time -> frame index at the stream's fps
+    dropInFlight();   // (pipelined mode: what was read ahead belongs to the old position)
     m_time = absolute ? tm : m_time + tm;
     if (m_time < 0.0f)
         m_time = 0.0f;

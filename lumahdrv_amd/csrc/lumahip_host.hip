@@ -775,7 +775,7 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     }
     const size_t nfl = (size_t)3 * w * h;
     if (c->es_head != c->es_tail)
-        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still pending: pop them first");
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push / lumahip_decode_stream_push are still pending: pop them first");
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
     if ((rc = dn_chunks_for(c, L.total)))
@@ -852,6 +852,8 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     int rc = check_geom(c, w, h, profile, c->q.cs);
     if (rc)
         return rc;
+    if (c->es_head != c->es_tail && c->es_dir != 0)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_decode_stream_push are in flight: pop them first");
     if (c->es_head - c->es_tail >= 2)
         return fail(c, LUMAHIP_ERR_STATE, "two frames are in flight already: lumahip_encode_stream_pop the oldest first");
     if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile))
@@ -909,6 +911,7 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     c->es_h = h;
     c->es_profile = profile;
     c->es_sc = sc;
+    c->es_dir = 0;
     c->es_head = seq + 1;
     return LUMAHIP_OK;
 }
@@ -917,8 +920,8 @@ extern "C" int lumahip_encode_stream_pop(lumahip_ctx *c, float *mean_lum)
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
-    if (c->es_head == c->es_tail)
-        return fail(c, LUMAHIP_ERR_STATE, "no frame is in flight");
+    if (c->es_head == c->es_tail || c->es_dir != 0)
+        return fail(c, LUMAHIP_ERR_STATE, "no encode frame is in flight");
     HIPCHK(c, hipSetDevice(c->device));
     const unsigned seq = c->es_tail;
     lumahip_ctx::Slot &sl = c->slot[seq % 3];
@@ -936,7 +939,92 @@ extern "C" int lumahip_encode_stream_pop(lumahip_ctx *c, float *mean_lum)
     return LUMAHIP_OK;
 }
 
-extern "C" int lumahip_encode_stream_pending(const lumahip_ctx *c) { return c ? (int)(c->es_head - c->es_tail) : 0; }
+extern "C" int lumahip_encode_stream_pending(const lumahip_ctx *c) { return (c && c->es_dir == 0) ? (int)(c->es_head - c->es_tail) : 0; }
+
+// The decode counterpart (LumaDecoder::decode() in a loop, lumadec.cpp:112-160): the download of frame i (12 B/pixel, the heavy
+// direction here) keeps the copy engine busy while the planes of frame i+1 go up and its kernel runs.
+extern "C" int lumahip_decode_stream_push(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], unsigned w,
+                                          unsigned h, int profile, float sc, float *rgb_out)
+{
+    if (!c || !rgb_out || !planes || !stride)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    int rc = check_geom(c, w, h, profile, c->q.cs);
+    if (rc)
+        return rc;
+    if (c->es_head != c->es_tail && c->es_dir != 1)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are in flight: pop them first");
+    if (c->es_head - c->es_tail >= 2)
+        return fail(c, LUMAHIP_ERR_STATE, "two frames are in flight already: lumahip_decode_stream_pop the oldest first");
+    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile))
+        return fail(c, LUMAHIP_ERR_STATE, "frame geometry changed while a frame is in flight: pop it first");
+    HIPCHK(c, hipSetDevice(c->device));
+    PlaneLayout L;
+    plane_layout(L, w, h, profile, stride);
+    for (int p = 0; p < 3; p++)
+        if (!planes[p] || stride[p] < L.row_bytes[p])
+            return fail(c, LUMAHIP_ERR_ARG, "plane %d: null or stride too small", p);
+    const size_t nfl = (size_t)3 * w * h;
+    if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, 1)))
+        return rc;
+    const unsigned seq = c->es_head;
+    lumahip_ctx::Slot &sl = c->slot[seq % 3];
+    unsigned char *dp[3] = {sl.d_planes + L.off[0], sl.d_planes + L.off[1], sl.d_planes + L.off[2]};
+    const size_t pfs[3] = {0, 0, 0};
+    if (seq >= 3) {
+        (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);   // planes of the slot's previous occupant consumed
+        (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);   // its floats downloaded
+    }
+    c->up_ramp = 0;
+    bool pinned_in = true;
+    for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++) {
+        pinned_in = pinned_in && host_range_is_pinned(planes[p], (size_t)(L.rows[p] - 1) * stride[p] + L.row_bytes[p]);
+        rc = xfer_h2d_2d(c, dp[p], stride[p], planes[p], stride[p], L.row_bytes[p], L.rows[p], c->s_h2d);
+    }
+    if (rc)
+        return rc;
+    (void)hipEventRecord(sl.h2d, c->s_h2d);
+    (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
+    hipStream_t saved = c->stream;
+    c->stream = c->s_kern;
+    rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
+    c->stream = saved;
+    if (rc)
+        return rc;
+    (void)hipEventRecord(sl.kern, c->s_kern);
+    (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
+    c->d2h_tag = seq;
+    rc = xfer_d2h_deferred(c, rgb_out, sl.d_frame, nfl * sizeof(float), c->s_d2h);
+    c->d2h_tag = 0;
+    if (rc)
+        return rc;
+    (void)hipEventRecord(sl.d2h, c->s_d2h);
+    if (pinned_in)   // (any pinned plane was read by the copy engine directly: it must be done with the caller's memory)
+        HIPCHK(c, hipEventSynchronize(sl.h2d));
+    c->es_w = w;
+    c->es_h = h;
+    c->es_profile = profile;
+    c->es_sc = sc;
+    c->es_dir = 1;
+    c->es_head = seq + 1;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decode_stream_pop(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (c->es_head == c->es_tail || c->es_dir != 1)
+        return fail(c, LUMAHIP_ERR_STATE, "no decode frame is in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned seq = c->es_tail;
+    lumahip_ctx::Slot &sl = c->slot[seq % 3];
+    c->es_tail = seq + 1;
+    const int rc = d2h_flush_upto(c, seq);
+    HIPCHK(c, hipEventSynchronize(sl.d2h));      // (a download into pinned memory has no chunks to flush)
+    return rc;
+}
+
+extern "C" int lumahip_decode_stream_pending(const lumahip_ctx *c) { return (c && c->es_dir == 1) ? (int)(c->es_head - c->es_tail) : 0; }
 
 extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *const *planes, const int stride[3],
                                           unsigned nframes, unsigned w, unsigned h, int profile, float sc,
@@ -959,7 +1047,7 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
     }
     const size_t nfl = (size_t)3 * w * h;
     if (c->es_head != c->es_tail)
-        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are still pending: pop them first");
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push / lumahip_decode_stream_push are still pending: pop them first");
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
     hipStream_t saved = c->stream;

@@ -111,6 +111,7 @@ struct lumahip_ctx {
     size_t dn_chunk = (size_t)8 << 20;  // bytes per download chunk (grows with the frames of the pipelined encode paths)
     // frames pushed with lumahip_encode_stream_push and not yet popped: sequence numbers [es_tail, es_head), frame j in slot[j % 3]
     unsigned es_head = 0, es_tail = 0;
+    int es_dir = 0;                // 0: the frames in flight were pushed by lumahip_encode_stream_push, 1: by lumahip_decode_stream_push
     unsigned es_w = 0, es_h = 0;
     int es_profile = 0;
     float es_sc = 1.0f;

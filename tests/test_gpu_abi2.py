@@ -291,12 +291,14 @@ def test_many_gpu_layer_from_cpp(tmp_path):
 def test_pipelined_encoder_writes_the_same_stream(tmp_path, w, h, frames, cs, bits, profile):
     """tests/cpp/pipelined_encoder.cpp: LumaEncoder::setPipelined(true) (lumahip_encode_stream_push / _pop: frame i+1 goes up
     before frame i is completed) writes byte for byte the stream of the synchronous mode, delivers every frame exactly one
-    encode() late, lets the caller overwrite its frame at once, and the C ABI refuses what it documents as refused."""
+    encode() late, lets the caller overwrite its frame at once, and the C ABI refuses what it documents as refused; LumaDecoder::
+    setPipelined(true) (lumahip_decode_stream_push / _pop) returns the synchronous decoder's frames bit for bit, in order."""
     exe = _build_cpp(str(tmp_path), "pipelined_encoder")
     r = subprocess.run([exe, str(tmp_path), str(w), str(h), str(frames), str(cs), str(bits), str(profile)], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "OK streams identical: %d frames" % frames in r.stdout and "OK stream rules" in r.stdout
+    assert "OK pipelined decode: %d frames identical" % frames in r.stdout
 
 
 def test_many_gpu_layer_through_ctypes_against_the_oracle(oracle_mod):

@@ -136,6 +136,22 @@ int main(int argc, char **argv)
             if (lumahip_decode_frame_host(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, out.data()) != LUMAHIP_OK)
                 throw LumaException(lumahip_last_error(ctx));
         const double dec = n * px / (now() - t0) / 1e6;
+        // the same per-frame decode through the streaming entry points (what LumaDecoder::setPipelined(true) calls): frame i+1 is
+        // uploaded and launched before frame i is completed
+        std::vector<float> out2((size_t)3 * w * h);
+        double dec_pipe = 0.0;
+        {
+            float *ob[2] = {out.data(), out2.data()};
+            (void)lumahip_decode_stream_push(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, ob[0]);
+            t0 = now();
+            for (int i = 1; i <= n; i++) {
+                if (lumahip_decode_stream_push(ctx, cpl, st, w, h, (int)prm.profile, prm.preScaling, ob[i & 1]) != LUMAHIP_OK ||
+                    lumahip_decode_stream_pop(ctx) != LUMAHIP_OK)
+                    throw LumaException(lumahip_last_error(ctx));
+            }
+            dec_pipe = n * px / (now() - t0) / 1e6;
+            (void)lumahip_decode_stream_pop(ctx);
+        }
         // batched decode into pageable frames (4 distinct outputs)
         std::vector<std::vector<float>> outs(4, std::vector<float>((size_t)3 * w * h));
         std::vector<const unsigned char *> dpl(3 * (size_t)n);
@@ -158,8 +174,8 @@ int main(int argc, char **argv)
                     "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_frame\": %.1f, "
                     "\"LumaEncoder_encode_registered_frame\": %.1f, "
                     "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
-                    "\"decode_frame_host_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
-                    w, h, n, pageable, pipelined, registered, batch, batch_pageable, dec, dec_batch);
+                    "\"decode_frame_host_pageable\": %.1f, \"decode_stream_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
+                    w, h, n, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;

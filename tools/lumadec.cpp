@@ -3,6 +3,7 @@
 // fused HIP kernel) and is written with ExrInterface::writeFrame.  The input is this build's raw Luma plane stream
 // (.lhs) instead of VP9 in Matroska (out of scope; a LumaPlaneSource for it attaches upstream of the decoder).
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "exr_interface.h"
@@ -23,6 +24,10 @@ int main(int argc, char *argv[])
         if (!opt.parse(argc, argv))
             return 1;
         LumaDecoder decoder(input.c_str(), verbose);
+        // the reference's loop as it stands, with the decoder reading one frame ahead (the download of frame i runs under the read,
+        // upload and kernel of frame i+1; same frames in the same order; LUMADEC_PIPELINED=0 switches it off)
+        const char *pipeEnv = std::getenv("LUMADEC_PIPELINED");
+        decoder.setPipelined(!(pipeEnv && std::atoi(pipeEnv) == 0));
         int done = 0;
         for (int f = 1;; f++) {
             std::fprintf(stderr, "Decoding frame %d... ", f);
