@@ -427,7 +427,7 @@ def test_pipelined_batch_host_entry_points(L, oracle_mod):
 
 
 def test_pageable_buffers_are_staged_in_chunks_with_padded_strides(L, oracle_mod):
-    """Pageable caller memory moves through 8 MiB pinned chunks (lumahip_capi.hip: xfer_h2d_2d / xfer_d2h_2d).  A 4K
+    """Pageable caller memory moves through 8 MiB pinned chunks (lumahip_host.hip: xfer_h2d_2d / xfer_d2h_2d).  A 4K
     frame with row strides wider than the rows makes every plane a multi-chunk, row-by-row transfer in both directions;
     results equal the oracle's and the padding bytes of the caller's planes are never written."""
     o = oracle_mod
@@ -761,7 +761,7 @@ def test_random_monotone_tables_through_the_encode_kernel(L, oracle_mod):
 
 @pytest.mark.parametrize("name,nframes", [("pq11_luv8", 8), ("log12_luv8", 8), ("pq10_ycbcr10", 20)])
 def test_long_batched_launches_are_bit_exact(L, oracle_mod, name, nframes):
-    """Batched launches long enough for the launch-geometry rules of lumahip_capi.hip: grid_for / block_threads_for (3
+    """Batched launches long enough for the launch-geometry rules of lumahip_launch.hip: grid_for / block_threads_for (3
     workgroups per CU for the 256-thread encode kernels, 256-thread workgroups for LOG-12, 5 per CU for the 4:2:0 16-bit
     decode kernels, 18 / 12 static shares per CU for YCbCr) -- every frame of the batch against the oracle, planes and
     decoded floats, bit for bit."""
