@@ -78,9 +78,10 @@ int lumahip_sync(lumahip_ctx *ctx);
  * entry points: 0..32, default 3), "host_bands" (row bands the single-frame _host entry points split a frame into so that
  * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "band_taper" (each band's rows in
  * per cent of the previous band's, 10..100, default 70: the last band is small, so little is left to do once the upload ends), "ycbcr_tables" (0: the
- * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
+ * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables),
+ * "half_table" (0 / 1 / 2: when the YCbCr encode kernels use the half-input table, see lumahip_ycbcr_half_table_host).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
  * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
- * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_BAND_TAPER, LUMAHIP_YCBCR_TABLES set the
+ * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_BAND_TAPER, LUMAHIP_YCBCR_TABLES, LUMAHIP_HALF_TABLE set the
  * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
 int lumahip_tune(lumahip_ctx *ctx, const char *key, long value);
 
@@ -118,6 +119,27 @@ int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t 
  * instead of evaluating PQenc per pixel. */
 int lumahip_ycbcr_luma_index_host(const float *lut, size_t n, float maxLum, int info[5], uint32_t *rec_out, size_t rec_cap);
 int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float maxLum, float *out);
+
+/* Half-input table of the YCbCr encode kernels.  The reference's EXR reader hands the encoder binary16 values widened to float
+ * (src/exr_interface.cpp:77-146 reads Imf::Rgba), and for such an input x the non-linear colour value
+ * PQenc(std::max(x * sc, 1e-10f)) (src/luma_quantizer.cpp:331-333, 491-494) depends on x's 16 bits only: per (preScaling sc,
+ * maxLum) the library tabulates it with the host libm for the 31745 halves +0 ... +inf (out[i], i = the half's bit pattern;
+ * negative halves share entry 0) and the kernels replace the six powf of a pixel by three LDS gathers.  Pixels whose inputs
+ * are not binary16 values (or NaN) are evaluated per pixel as before, inside the same launch; results are identical either
+ * way.  lumahip_ycbcr_half_table_host is host-only (no GPU, no context; cap >= 31745 floats) and returns
+ * LUMAHIP_ERR_UNSUPPORTED when the table is not usable for the pair (sc not positive and finite, or an entry outside
+ * [7e-7, 2] that is not a NaN, maxLum outside [1e-6, 1e9]) -- the kernels then evaluate every pixel.  lumahip_half_table_info reports for the context's
+ * quantizer and a preScaling: info[0] = 1 when encode launches without per-frame statistics are eligible for the half-input
+ * kernels, info[1] = their LDS bytes per workgroup, info[2] = device copies of the table the context holds (one per (sc,
+ * maxLum) seen, at most four), info[3] = table entries, info[4] = launches that took the half-input kernels so far, info[5] =
+ * eligible launches that ran the per-pixel kernels instead because the stream did not look like binary16 data.
+ * lumahip_tune("half_table", v): 0 = never use the table; 1 (default) = use it while the stream looks like binary16 data -- a
+ * launch most of whose pixels are full-precision floats costs 1.4 x the per-pixel kernels' time on the table kernels, so the
+ * kernels report such launches (one word of pinned host memory, no synchronisation) and the following 16 eligible launches run
+ * per pixel before one launch tries the table again, the pause doubling up to 1024 launches while the reports continue;
+ * 2 = always use it.  None of this changes a result. */
+int lumahip_ycbcr_half_table_host(float sc, float maxLum, float *out, size_t cap);
+int lumahip_half_table_info(lumahip_ctx *ctx, float sc, int info[6]);
 
 /* introspection of the search index built for the current LUT (tests):
  * info[0] = mode (0 = literal bisection, table in LDS; 2 = literal bisection, table read from global memory

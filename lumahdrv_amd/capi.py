@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
     "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
@@ -123,6 +123,8 @@ def lib():
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_ycbcr_luma_index_host.argtypes = [vp, sz, f, C.POINTER(i), vp, sz]
     L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
+    L.lumahip_ycbcr_half_table_host.argtypes = [f, f, vp, sz]
+    L.lumahip_half_table_info.argtypes = [vp, f, C.POINTER(i)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
     L.lumahip_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
@@ -283,6 +285,20 @@ def ycbcr_ytab(lut: np.ndarray, max_lum: float) -> np.ndarray:
     return out
 
 
+HALF_TABLE_LEN = 0x7C00 + 1
+
+
+def ycbcr_half_table(sc: float, max_lum: float):
+    """host-only: the half-input table of the YCbCr encode kernels for (preScaling, maxLum), or None when the pair does not qualify"""
+    out = np.empty(HALF_TABLE_LEN, dtype=np.float32)
+    rc = lib().lumahip_ycbcr_half_table_host(sc, max_lum, out.ctypes.data, out.size)
+    if rc == ERR_UNSUPPORTED:
+        return None
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_ycbcr_half_table_host failed")
+    return out
+
+
 def thresh_lookup(ix, v: np.ndarray) -> np.ndarray:
     """numpy evaluation of the record table exactly as the kernels do it (sign-set NaNs excluded by the caller)"""
     b = np.ascontiguousarray(v, dtype=np.float32).view(np.int32)
@@ -346,6 +362,11 @@ class Context:
         a = (C.c_int * 5)()
         self._chk(self.L.lumahip_quantizer_info(self.h, a))
         return dict(mode=a[0], mant_bits=a[1], buckets=a[2], shift=a[3], lds_bytes=a[4])
+
+    def half_table_info(self, sc: float):
+        a = (C.c_int * 6)()
+        self._chk(self.L.lumahip_half_table_info(self.h, sc, a))
+        return dict(used=bool(a[0]), lds_bytes=a[1], device_copies=a[2], entries=a[3], table_launches=a[4], backoff_launches=a[5])
 
     # ---- host entry points (numpy)
     def encode_frame(self, rgb: np.ndarray, sc=1.0, profile=2, align=32, want_transformed=False, strides=None):

@@ -134,4 +134,32 @@ void ycbcr_ytab_host(const float *lut, size_t n, float Lmax, float *out)
     }
 }
 
+
+// Encode side, binary16 inputs (the reference's EXR reader produces nothing else, src/exr_interface.cpp:77-146): entry i, i the
+// bit pattern of a half in +0 ... +inf, holds PQenc(std::max(x * sc, 1e-10f)) (src/luma_quantizer.cpp:331-333, 491-494) for that
+// half's value x -- the non-linear R' / G' / B' of a pixel as a function of 16 input bits, per (sc, Lmax).  Returns false, and
+// the kernels keep evaluating PQenc per pixel, unless sc is a positive finite number, Lmax lies in [1e-6, 1e9] and every entry is a NaN or lies in
+// [7e-7, 2]: the range the kernels' short divisions behind the table are licensed for (luma_device.hpp ycbcr_fwd_half_n).
+bool ycbcr_half_table_host(float sc, float Lmax, float *out)
+{
+    if (!(sc > 0.0f) || !(sc <= 3.0e38f) || !(Lmax >= 1e-6f && Lmax <= 1e9f))   // (the peak range of the kernels' general path, ycbcr_fwd_n)
+        return false;
+    for (unsigned i = 0; i <= 0x7C00u; i++) {
+        // binary16 -> binary32, exactly
+        const unsigned e = i >> 10, m = i & 0x3ffu;
+        float x;
+        if (e == 0)
+            x = ldexpf((float)m, -24);
+        else if (e == 31)
+            x = INFINITY;  // i == 0x7C00, m == 0
+        else
+            x = ldexpf((float)(m | 0x400u), (int)e - 25);
+        const float v = pq_encode_host(Lmax, std::max(x * sc, 1e-10f));
+        out[i] = v;
+        if (!(v != v) && !(v >= 7e-7f && v <= 2.0f))
+            return false;
+    }
+    return true;
+}
+
 }  // namespace lh

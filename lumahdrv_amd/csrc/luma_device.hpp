@@ -123,19 +123,24 @@ LH_DEV float div_255_pos(float a)
 //              division when sc == 1.0f, x/1.0f being exact).
 // ---------------------------------------------------------------------------------------------------
 
-struct XformConst {
+// Tab: which powf tables the YCbCr path reads -- PowfTablesWide (33 KiB, one LDS read per log2) everywhere except the
+// half-input encode kernels, whose LDS belongs to the 124 KiB table of luma_device.hpp half_lookup and whose (rare) general
+// path therefore runs on the 768-byte PowfTables.  Same arithmetic, same results (pow_glibc.hpp).
+template <typename Tab>
+struct XformConstT {
     float sc;               // preScaling
     float Lmax;             // PQ peak for the YCbCr path
-    const PowfTablesWide *pw;  // powf tables (LDS copy), YCbCr only
+    const Tab *pw;          // powf tables (LDS copy), YCbCr only
     // refined reciprocals (rcp_nr) of the YCbCr path's constant divisors, computed once per thread instead of once
     // per division: div_nr_r(a, b, rcp_nr(b)) is div_nr(a, b) by definition
     float rLmax, r18814, r14746, r224, r0678;
 };
+using XformConst = XformConstT<PowfTablesWide>;
 
-template <int CS>
-LH_DEV XformConst make_xform_const(float sc, float Lmax, const PowfTablesWide *pw)
+template <int CS, typename Tab = PowfTablesWide>
+LH_DEV XformConstT<Tab> make_xform_const(float sc, float Lmax, const Tab *pw)
 {
-    XformConst k;
+    XformConstT<Tab> k;
     k.sc = sc;
     k.Lmax = Lmax;
     k.pw = pw;
@@ -152,14 +157,16 @@ LH_DEV XformConst make_xform_const(float sc, float Lmax, const PowfTablesWide *p
 
 // LumaQuantizer::transformPQ, src/luma_quantizer.cpp:485-501.  The constants are double literals
 // narrowed to `const float` in the reference; 1.0f/m and 1.0f/n are single fp32 divisions.
-LH_DEV float pq_encode(float val, const XformConst &k)
+template <typename K>
+LH_DEV float pq_encode(float val, const K &k)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float Lp = powf_glibc(div_ieee(val, k.Lmax), n, *k.pw);
     return powf_glibc(div_ieee(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw);
 }
 
-LH_DEV float pq_decode(float val, const XformConst &k)
+template <typename K>
+LH_DEV float pq_decode(float val, const K &k)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float Vp = powf_glibc(val, 1.0f / m, *k.pw);
@@ -178,7 +185,8 @@ struct SlowAcc {
     uint32_t umin = 0xffffffffu;  // running unsigned min of (bits(x) - 1) over arguments that must be +0 or >= pw_range_low
     bool flag = false;
 };
-LH_DEV bool slow_any(const SlowAcc &a, const XformConst &k)
+template <typename K>
+LH_DEV bool slow_any(const SlowAcc &a, const K &k)
 {
     return a.flag || a.umax >= pw_range_limit(*k.pw) || a.umin < pw_range_low(*k.pw) - 1u;
 }
@@ -189,8 +197,8 @@ LH_DEV bool slow_any(const SlowAcc &a, const XformConst &k)
 // normal float (or +0): |n*log2(x1)| <= 20.4, so Lp in {0} u [7e-7, 1.4e6]; c1 + c2*Lp in [0.83, 2.7e7] and
 // 1 + c3*Lp in [1, 2.7e7] are normal, their quotient x2 lies in [0.8359, 1.0088], and m*log2(x2) in [-20.4, 1.0]:
 // the second power needs no test at all, and the result lies in [7.3e-7, 1.995].
-template <bool ANYVAL>
-LH_DEV float pq_encode_r(float val, const XformConst &k, SlowAcc &acc)
+template <bool ANYVAL, typename K>
+LH_DEV float pq_encode_r(float val, const K &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float x1 = div_nr_r(val, k.Lmax, k.rLmax);
@@ -211,8 +219,8 @@ LH_DEV float pq_encode_r(float val, const XformConst &k, SlowAcc &acc)
 // a normal float -- it is a sum / difference of floats whose granularity is far above 2^-126 (ycbcr_inv), never a
 // denormal; Vp <= c1 gives a quotient of exactly 0 (ZERO) and Vp just above c1 one small enough for |log2|/n >= 126
 // (CHECK_E); the quotient itself is 0 or in [3e-9, 6.4], a normal float.
-template <bool BOUNDED>
-LH_DEV float pq_decode_r(float val, const XformConst &k, SlowAcc &acc)
+template <bool BOUNDED, typename K>
+LH_DEV float pq_decode_r(float val, const K &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
     const float Vp = powf_regular<!BOUNDED, false, false>(val, 1.0f / m, *k.pw, acc.flag);
@@ -300,8 +308,8 @@ LH_DEVS void xform_fwd<CS_PACK>(float r, float g, float b, const XformConst &, f
 // build_thresh_index_fn) -- two powf, a division and the table search collapse into one 4-byte LDS gather.  y is >= +0 or
 // NaN (a sum of non-negative products), so t is >= 16 or NaN, which is what the NONNEG form of the record search needs;
 // beyond t ~ 508 and for NaN the reference's arithmetic ends in code maxVal, and so does the records' top bucket.
-template <bool REGULAR, bool YCODE = false>
-LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0, float &c1, float &c2, SlowAcc &slow)
+template <bool REGULAR, bool YCODE = false, typename K>
+LH_DEV void ycbcr_fwd(float r, float g, float b, const K &k, float &c0, float &c1, float &c2, SlowAcc &slow)
 {
     float R, G, B;
     if constexpr (REGULAR) {
@@ -336,8 +344,8 @@ LH_DEV void ycbcr_fwd(float r, float g, float b, const XformConst &k, float &c0,
 // N pixels at once: straight-line evaluation first; if any of them had a NaN / inf / denormal / out-of-range power
 // argument (rare), all N are redone with the complete powf.  Both produce identical bits wherever the straight-line
 // form applies.  One flag and one branch per thread and unit, not per pixel.
-template <int N, bool YCODE = false>
-LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], const XformConst &k, float (&c0)[N],
+template <int N, bool YCODE = false, typename K>
+LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], const K &k, float (&c0)[N],
                         float (&c1)[N], float (&c2)[N])
 {
     SlowAcc slow;
@@ -349,6 +357,65 @@ LH_DEV void ycbcr_fwd_n(const float (&r)[N], const float (&g)[N], const float (&
         for (int i = 0; i < N; i++)  // not unrolled: cold code
             ycbcr_fwd<false, YCODE>(r[i], g[i], b[i], k, c0[i], c1[i], c2[i], slow);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Half-input table (YCbCr encode).  The reference's EXR reader delivers binary16 values only (src/exr_interface.cpp:77-146
+// reads Imf::Rgba and widens), and for such an input x the non-linear value
+//     R' = PQenc(std::max(x * sc, 1e-10f))                                     (src/luma_quantizer.cpp:331-333, 491-494)
+// is a function of x's 16 bits alone once the stream's preScaling `sc` and peak Lmax are fixed.  The host tabulates it with
+// its libm -- the function the reference calls -- for the 31745 halves +0 ... +inf (host_lut.cpp ycbcr_half_table_host;
+// HALF_TABLE_LEN entries, 124 KiB, staged in LDS), and the six powf of a pixel's three channels become three LDS gathers:
+//   * index = the binary16 bit pattern of x, sign-extended and clamped to [0, 0x7C00]: every negative half (-0 and -inf
+//     included) reads entry 0, which is right because x * sc <= -0 < 1e-10 for the sc > 0 the table is built for, so the
+//     reference's std::max answers 1e-10 exactly as it does for x = +0;
+//   * `miss` is raised when x is not a half (the round trip through binary16 changes it: any rounding, overflow to inf, or a
+//     NaN of either sign, which compares unequal to everything): the caller then evaluates the pixel's unit with the general
+//     functions.  -0 == -0 and inf == inf compare equal, so those stay on the table.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HALF_TABLE_LEN = 0x7C00 + 1;
+
+LH_DEV float half_lookup(float x, const float *tab, bool &miss)
+{
+    const _Float16 h = (_Float16)x;  // v_cvt_f16_f32, round to nearest even
+    miss = miss || ((float)h != x);
+    // (bits << 16) >> 14 (arithmetic) = 4 * the sign-extended pattern: the byte offset, clamped in one v_med3_i32
+    const int off = (int)((uint32_t)__builtin_bit_cast(unsigned short, h) << 16) >> 14;
+    const int o = min(max(off, 0), 4 * 0x7C00);
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(tab) + o);
+}
+
+// The unit's pixels through the half table; c0 is always the YCODE form t = 219 y + 16 (see ycbcr_fwd).  r, g, b are the RAW
+// inputs (before `* sc`, which the table has folded in).  Every table entry is either NaN or lies in [7e-7, 2] -- the host
+// checks that before it hands the table out -- which is the operand range ycbcr_fwd<REGULAR> licenses its short divisions
+// for (and a NaN gives NaN through either form of division: code maxVal / maxC as in the reference).
+// Returns whether this thread's unit took the general path.
+template <int N, typename K>
+LH_DEV bool ycbcr_fwd_half_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], const K &k, const float *tab,
+                             float (&c0)[N], float (&c1)[N], float (&c2)[N])
+{
+    bool miss = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float R = half_lookup(r[i], tab, miss);
+        const float G = half_lookup(g[i], tab, miss);
+        const float B = half_lookup(b[i], tab, miss);
+        const float y = (0.2627f * R + 0.6780f * G) + 0.0593f * B;
+        c0[i] = 219.0f * y + 16.0f;
+        c1[i] = div_255_pos(224.0f * div_nr_r(B - y, 1.8814f, k.r18814) + 128.0f);
+        c2[i] = div_255_pos(224.0f * div_nr_r(R - y, 1.4746f, k.r14746) + 128.0f);
+    }
+    if (__builtin_expect(miss, 0)) {
+        // some input of this thread's unit is not a half: the whole unit again through the general functions
+        float rs[N], gs[N], bs[N];
+        for (int i = 0; i < N; i++) {
+            rs[i] = r[i] * k.sc;
+            gs[i] = g[i] * k.sc;
+            bs[i] = b[i] * k.sc;
+        }
+        ycbcr_fwd_n<N, true>(rs, gs, bs, k, c0, c1, c2);
+    }
+    return miss;
 }
 
 template <>
@@ -377,8 +444,8 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 // YT: c0 is already y = (255 PQenc(table value) - 16) / 219, read from the per-stream table the host built with its libm
 // (host_lut.cpp ycbcr_ytab_host; QuantDev::ytab): the first of the four PQ evaluations of a pixel depends on the luminance
 // CODE alone, so it is done once per table entry and stream instead of once per pixel.
-template <bool REGULAR, bool YT = false>
-LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &r, float &g, float &b, SlowAcc &slow)
+template <bool REGULAR, bool YT = false, typename K>
+LH_DEV void ycbcr_inv(float c0, float c1, float c2, const K &k, float &r, float &g, float &b, SlowAcc &slow)
 {
     float y, blue, red, green;
     if constexpr (REGULAR) {
@@ -421,8 +488,8 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const XformConst &k, float &
     }
 }
 
-template <int N, bool YT = false>
-LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const XformConst &k, float (&r)[N],
+template <int N, bool YT = false, typename K>
+LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
                         float (&g)[N], float (&b)[N])
 {
     SlowAcc slow;

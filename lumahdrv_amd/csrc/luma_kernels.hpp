@@ -14,6 +14,8 @@
 // per-frame statistics (float atomics).
 #pragma once
 
+#include <type_traits>
+
 #include "luma_device.hpp"
 
 
@@ -48,6 +50,12 @@ struct EncArgs {
     int bps;              // bytes per sample: 1 or 2
     int aligned;          // 1: vector stores allowed
     float *stats;         // nullable: per frame STATS_SLOTS partial {sum,min,max} triples (k_fold_stats folds them)
+    const float *half;    // LM == 6 only: the half-input table of this (sc, Lmax), HALF_TABLE_LEN floats padded to 16 B (luma_device.hpp half_lookup)
+    // LM == 6 only, nullable: a word in host-visible memory that a workgroup overwrites with half_seq when every unit of every
+    // one of its waves held inputs that are not halves -- the stream is not binary16 data and the host stops picking this
+    // kernel for a while (lumahip_core.hip half_policy).  Feedback only: nothing a launch computes depends on it.
+    uint32_t *half_flag;
+    uint32_t half_seq;
 };
 
 struct DecArgs {
@@ -72,23 +80,29 @@ struct DecArgs {
 
 // LDS layout: [powf tables (YCbCr only; FIRST, so that their addresses are immediates in the powf chains)]
 // [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B]
-// [u'v' table: maxC+1 floats (Lu'v' decode only), see luv_chroma_uv].
+// [u'v' table: maxC+1 floats (Lu'v' decode only), see luv_chroma_uv | half-input table (YCbCr encode, LM == 6)].
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
-enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16, STAGE_YT = 32 };
+// STAGE_POWFN: the 768-byte powf tables instead of the wide ones (the half-input kernels: their LDS belongs to the half table).
+enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16, STAGE_YT = 32, STAGE_POWFN = 64, STAGE_HALF = 128 };
 
 // fill the LDS copy of the powf tables (pow_glibc.hpp); the caller synchronises
-LH_DEV void stage_powf_tables(PowfTablesWide *t)
+LH_DEV void stage_powf_tables(PowfTables *t)
 {
     const double lt[16][2] = LH_POWF_LOG2_TAB;
     const uint64_t et[32] = LH_POWF_EXP2_TAB;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
     if (tid < 16) {
         t->log2_tab[tid][0] = lt[tid][0];
         t->log2_tab[tid][1] = lt[tid][1];
     }
     if (tid < 32)
         t->exp2_tab[tid] = et[tid];
-    for (int e = tid; e < 2048; e += nt)
+}
+LH_DEV void stage_powf_tables(PowfTablesWide *t)
+{
+    const double lt[16][2] = LH_POWF_LOG2_TAB;
+    stage_powf_tables(static_cast<PowfTables *>(t));
+    for (int e = threadIdx.x; e < 2048; e += blockDim.x)
         pw_wide_entry(e, lt, t->wide[e][0], t->wide[e][1]);
 }
 
@@ -97,17 +111,32 @@ LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15
 
 // offset of the search table / records behind the powf tables
 template <int WHAT>
-constexpr int lds_table_offset() { return (WHAT & STAGE_POWF) ? (int)sizeof(PowfTablesWide) : 0; }
+constexpr int lds_table_offset()
+{
+    return (WHAT & STAGE_POWF) ? (int)sizeof(PowfTablesWide) : (WHAT & STAGE_POWFN) ? (int)sizeof(PowfTables) : 0;
+}
+
+constexpr int lds_half_bytes() { return (HALF_TABLE_LEN * 4 + 15) & ~15; }
 
 template <int WHAT>
-LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q)
+LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, const float *half = nullptr)
 {
-    static_assert(sizeof(PowfTablesWide) % 16 == 0, "the tables behind the powf tables must stay 16-byte aligned");
+    static_assert(sizeof(PowfTablesWide) % 16 == 0 && sizeof(PowfTables) % 16 == 0, "the tables behind the powf tables must stay 16-byte aligned");
     static_assert(!((WHAT & STAGE_LUT) && (WHAT & STAGE_REC)), "one search table per kernel");
+    static_assert(!((WHAT & STAGE_POWF) && (WHAT & STAGE_POWFN)), "one set of powf tables per kernel");
     const int tid = threadIdx.x, nt = blockDim.x;
     constexpr int off = lds_table_offset<WHAT>();
     if constexpr (WHAT & STAGE_POWF)
         stage_powf_tables(reinterpret_cast<PowfTablesWide *>(smem));
+    if constexpr (WHAT & STAGE_POWFN)
+        stage_powf_tables(reinterpret_cast<PowfTables *>(smem));
+    if constexpr (WHAT & STAGE_HALF) {
+        static_assert((WHAT & STAGE_REC) && !(WHAT & (STAGE_UV | STAGE_YT)), "the half-input table sits behind the records");
+        const float4 *g = reinterpret_cast<const float4 *>(half);
+        float4 *s4 = reinterpret_cast<float4 *>(smem + off + lds_rec_bytes(q));
+        for (int i = tid; i < lds_half_bytes() / 16; i += nt)
+            s4[i] = g[i];
+    }
     if constexpr (WHAT & STAGE_LUT) {
         // table length + pad is a multiple of 4 floats on the host side (buffer is padded to 16 B)
         const int n4 = lds_lut_bytes(q) / 16;
@@ -272,7 +301,8 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 // ---- ENCODE ---------------------------------------------------------------------------------------
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
 // LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global;
-// 5 = YCbCr only: records in LDS for the composite luma -> code function, channel 0 carries the luma y, luma_device.hpp ycbcr_fwd).
+// 5 = YCbCr only: records in LDS for the composite luma -> code function, channel 0 carries the luma y, luma_device.hpp ycbcr_fwd;
+// 6 = 5 + the half-input table in LDS: R', G', B' are three gathers for pixels whose inputs are binary16 values, luma_device.hpp half_lookup).
 //
 // Software pipeline: the six (VW=4: 16-byte) loads of the thread's NEXT unit are issued at the end of the current
 // unit's iteration, one full iteration before they are needed (without this the kernel sat at ~45 % SQ_WAIT_ANY,
@@ -355,11 +385,14 @@ LH_DEV void stats_flush(EncStats &st, float *stats, int tx)
 }
 
 // colour transform of one unit (row-major pixel order inside the unit: j = r*VW + i)
-template <int CS, int VW, bool YCODE = false>
-LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k, float (&c0)[2 * VW],
-                          float (&c1)[2 * VW], float (&c2)[2 * VW], EncStats &st)
+// HALF (YCbCr, LM == 6): the pixels go through the half-input table at `s_half` (LDS), which has `* sc` folded in
+// Returns (HALF only) whether this thread's unit fell back to the general functions.
+template <int CS, int VW, bool YCODE = false, bool HALF = false, typename K>
+LH_DEV bool enc_transform(EncUnit<VW> &u, const EncArgs &a, const K &k, float (&c0)[2 * VW],
+                          float (&c1)[2 * VW], float (&c2)[2 * VW], EncStats &st, const float *s_half = nullptr)
 {
-    if (k.sc != 1.0f) {  // wave-uniform; x*1.0f == x, so the multiply is skipped for the default preScaling
+    bool general = false;
+    if (!HALF && k.sc != 1.0f) {  // wave-uniform; x*1.0f == x, so the multiply is skipped for the default preScaling
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -378,7 +411,10 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
                 g8[r * VW + i] = u.in[1][r][i];
                 b8[r * VW + i] = u.in[2][r][i];
             }
-        ycbcr_fwd_n<2 * VW, YCODE>(r8, g8, b8, k, c0, c1, c2);  // one "redo with the complete powf" decision per unit
+        if constexpr (HALF)
+            general = ycbcr_fwd_half_n<2 * VW>(r8, g8, b8, k, s_half, c0, c1, c2);
+        else
+            ycbcr_fwd_n<2 * VW, YCODE>(r8, g8, b8, k, c0, c1, c2);  // one "redo with the complete powf" decision per unit
     } else {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -395,6 +431,7 @@ LH_DEV void enc_transform(EncUnit<VW> &u, const EncArgs &a, const XformConst &k,
             st.mx = fmaxf(st.mx, c0[j]);
         }
     }
+    return general;
 }
 
 // quantize + subsample + pack + store one transformed unit
@@ -486,13 +523,20 @@ template <int CS, bool SUB, int VW, int LM>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(LM != 5 || CS == CS_YCBCR, "the composite records belong to the YCbCr kernels");
-    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 5) ? STAGE_REC : 0) | (CS == CS_YCBCR ? STAGE_POWF : 0);
-    stage_tables<WHAT>(smem, a.q);
+    static_assert((LM != 5 && LM != 6) || CS == CS_YCBCR, "the composite records belong to the YCbCr kernels");
+    constexpr bool HALF = (LM == 6);
+    __shared__ int s_votes[HALF ? 2 : 1];   // HALF: waves of this workgroup that had units / that left the table in every one
+    if (HALF && threadIdx.x == 0)
+        s_votes[0] = s_votes[HALF ? 1 : 0] = 0;   // (stage_tables synchronises)
+    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 5 || LM == 6) ? STAGE_REC : 0) |
+                         (CS == CS_YCBCR ? (HALF ? STAGE_POWFN | STAGE_HALF : STAGE_POWF) : 0);
+    stage_tables<WHAT>(smem, a.q, a.half);
 
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());        // LM == 0
-    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem + lds_table_offset<WHAT>());  // LM == 3
-    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTablesWide *>(smem));
+    const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem + lds_table_offset<WHAT>());  // LM == 3, 5, 6
+    const float *s_half = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_rec_bytes(a.q));  // LM == 6
+    using PowTab = typename std::conditional<HALF, PowfTables, PowfTablesWide>::type;
+    const XformConstT<PowTab> k = make_xform_const<CS, PowTab>(a.sc, a.q.Lmax, reinterpret_cast<const PowTab *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -509,6 +553,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     // before the stores (round 1) measured 1.0-1.3 % slower HBM-fed, same-box, 5 of 5 interleaved rounds: with the
     // stores first the write bursts of a wave are not queued behind its own 6 KiB of reads.
     EncUnit<VW> u;
+    int n_units = 0, n_general = 0;   // HALF: this wave's units, and those in which some lane left the table (wave-uniform)
     enc_load<VW>(u, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
         if (a.stats) {
@@ -521,10 +566,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         const bool valid = u.valid;
         const int f = u.f, ux = u.ux, uy = u.uy;
         float c0[2 * VW], c1[2 * VW], c2[2 * VW];
+        bool general = false;
         if (valid)
-            enc_transform<CS, VW, LM == 5>(u, a, k, c0, c1, c2, st);
+            general = enc_transform<CS, VW, LM == 5 || LM == 6, HALF>(u, a, k, c0, c1, c2, st, s_half);
+        if constexpr (HALF) {
+            n_units++;
+            n_general += __builtin_amdgcn_ballot_w64(general) != 0;
+        }
         if (valid) {
-            if constexpr (LM == 3 || LM == 5)
+            if constexpr (LM == 6)
+                enc_emit<CS, SUB, VW, 5>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
+            else if constexpr (LM == 3 || LM == 5)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
             else if constexpr (LM == 4)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, a.q.rec);
@@ -537,6 +589,22 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     }
     if (a.stats)
         stats_flush(st, a.stats, tx);
+    if constexpr (HALF) {
+        // Feedback: this workgroup reports "not binary16 data" when EVERY unit of EVERY one of its waves had a lane on the
+        // general path -- with 1 % of the pixels off the table that is nearly every workgroup (and the table kernel then costs
+        // 1.4 x the per-pixel one), with 0.1 % (where the table still wins) a wave sees such a unit 40 % of the time and
+        // sixteen waves in a row essentially never do.
+        if (a.half_flag) {   // (kernel argument: uniform)
+            if (tx == 0 && n_units > 0) {
+                atomicAdd(&s_votes[0], 1);
+                if (n_general == n_units)
+                    atomicAdd(&s_votes[1], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && s_votes[0] > 0 && s_votes[0] == s_votes[1])
+                __hip_atomic_store(a.half_flag, a.half_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- DECODE ---------------------------------------------------------------------------------------

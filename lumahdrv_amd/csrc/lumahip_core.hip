@@ -68,7 +68,7 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
                                               {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_BAND_TAPER", "band_taper"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
-                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}};
+                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}, {"LUMAHIP_HALF_TABLE", "half_table"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
                 (void)lumahip_tune(c, k[1], atol(e));
@@ -87,6 +87,9 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_rec_y);
     (void)hipFree(c->d_ytab);
+    for (auto &t : c->half_tabs)
+        (void)hipFree(t.d);
+    if (c->h_half_flag) (void)hipHostFree(c->h_half_flag);
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
@@ -256,6 +259,11 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->use_ycbcr_tables = v != 0;
         if (c->have_quant)
             return requantize(c);
+    } else if (k == "half_table") {
+        if (v < 0 || v > 2)
+            return fail(c, LUMAHIP_ERR_ARG, "half_table must be 0 (off), 1 (while the stream is binary16 data) or 2 (always)");
+        c->half_mode = (int)v;
+        c->half_backoff = c->half_backoff_len = 0;
     } else if (k == "host_bands") {
         if (v < 1 || v > lumahip_ctx::MAX_BANDS)
             return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
@@ -557,6 +565,142 @@ extern "C" int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float Lmax, f
         return LUMAHIP_ERR_ARG;
     ycbcr_ytab_host(lut, n, Lmax, out);
     return LUMAHIP_OK;
+}
+
+// The half-input table of the YCbCr encode kernels for this call's preScaling: a pure function of (sc, Lmax), 124 KiB, built
+// with the host libm in about a millisecond and kept -- per process on the host, per context on the device -- because a stream
+// encodes every frame with the same pair.  A context holds up to four device copies; launches that read an older copy may
+// still be queued on any stream or lane when a fifth pair turns up, so making room waits for the device first.
+namespace {
+struct HalfHostEntry {
+    float sc, Lmax;
+    bool ok;
+    std::shared_ptr<const std::vector<float>> tab;
+};
+std::mutex g_half_mutex;
+std::vector<HalfHostEntry> g_half_cache;
+
+HalfHostEntry cached_half_table(float sc, float Lmax)
+{
+    std::lock_guard<std::mutex> lk(g_half_mutex);
+    for (auto &e : g_half_cache)
+        if (memcmp(&e.sc, &sc, 4) == 0 && memcmp(&e.Lmax, &Lmax, 4) == 0)
+            return e;
+    HalfHostEntry e;
+    e.sc = sc;
+    e.Lmax = Lmax;
+    auto t = std::make_shared<std::vector<float>>((size_t)lds_half_bytes() / sizeof(float), 0.0f);
+    e.ok = ycbcr_half_table_host(sc, Lmax, t->data());
+    if (e.ok)
+        e.tab = t;
+    if (g_half_cache.size() >= 8)
+        g_half_cache.erase(g_half_cache.begin());
+    g_half_cache.push_back(e);
+    return e;
+}
+}  // namespace
+
+int half_table_for(lumahip_ctx *c, float sc, const float **tab)
+{
+    *tab = nullptr;
+    const float Lmax = c->q.Lmax;
+    for (auto &t : c->half_tabs)
+        if (memcmp(&t.sc, &sc, 4) == 0 && memcmp(&t.Lmax, &Lmax, 4) == 0) {
+            t.last_use = ++c->half_clock;
+            *tab = t.d;
+            return LUMAHIP_OK;
+        }
+    const HalfHostEntry h = cached_half_table(sc, Lmax);
+    if (c->half_tabs.size() >= 4) {
+        HIPCHK(c, hipDeviceSynchronize());
+        size_t old = 0;
+        for (size_t i = 1; i < c->half_tabs.size(); i++)
+            if (c->half_tabs[i].last_use < c->half_tabs[old].last_use)
+                old = i;
+        (void)hipFree(c->half_tabs[old].d);
+        c->half_tabs.erase(c->half_tabs.begin() + (long)old);
+    }
+    lumahip_ctx::HalfTab t;
+    t.sc = sc;
+    t.Lmax = Lmax;
+    t.last_use = ++c->half_clock;
+    if (h.ok) {
+        HIPCHK(c, hipMalloc(&t.d, (size_t)lds_half_bytes()));
+        // a blocking copy into memory nothing else knows yet: done when it returns, whatever stream the launch goes to
+        if (hipMemcpy(t.d, h.tab->data(), (size_t)lds_half_bytes(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(t.d);
+            return fail(c, LUMAHIP_ERR_HIP, "upload of the half-input table failed");
+        }
+    }
+    c->half_tabs.push_back(t);
+    *tab = t.d;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_ycbcr_half_table_host(float sc, float Lmax, float *out, size_t cap)
+{
+    if (!out || cap < (size_t)HALF_TABLE_LEN)
+        return LUMAHIP_ERR_ARG;
+    return ycbcr_half_table_host(sc, Lmax, out) ? LUMAHIP_OK : LUMAHIP_ERR_UNSUPPORTED;
+}
+
+extern "C" int lumahip_half_table_info(lumahip_ctx *c, float sc, int info[6])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_search_index(c))
+        return rc;
+    info[0] = info[1] = 0;
+    info[3] = HALF_TABLE_LEN;
+    if (ycbcr_composite_ready(c) && c->half_mode != 0 && lds_bytes(c, true, CS_YCBCR, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
+        const float *t = nullptr;
+        if (int rc = half_table_for(c, sc, &t))
+            return rc;
+        info[0] = t != nullptr;
+        info[1] = t ? (int)lds_bytes(c, true, CS_YCBCR, true, true) : 0;
+    }
+    info[2] = 0;
+    for (const auto &t : c->half_tabs)
+        info[2] += t.d != nullptr;
+    info[4] = (int)std::min<unsigned long>(c->half_launches, 0x7fffffffUL);
+    info[5] = (int)std::min<unsigned long>(c->half_backoff_launches, 0x7fffffffUL);
+    return LUMAHIP_OK;
+}
+
+// Which kernel an eligible launch takes (half_mode 1).  The half-input kernel evaluates units that hold anything but binary16
+// values with the general functions on top of its table reads -- 1.4 x the per-pixel kernels' time when EVERY pixel does that
+// (profiles/r04_half_miss_rate.txt), so a stream of full-precision floats (a PFS pipe rather than an EXR file) should not stay
+// on it.  The kernels report such launches through one word of pinned host memory (EncArgs::half_flag: plain stores, nobody
+// waits for them); a report sends the next 16 eligible launches to the per-pixel kernels, then one launch probes again, and
+// every further report in a row doubles the pause (up to 1024 launches: one probe in a thousand costs 0.04 %).  The word is
+// read when the next launch is issued, so the switch lags by however many launches the caller keeps in flight.
+bool half_policy(lumahip_ctx *c)
+{
+    if (c->half_mode != 1)
+        return c->half_mode == 2;
+    if (!c->h_half_flag) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_half_flag), 64, hipHostMallocDefault) != hipSuccess) {
+            c->h_half_flag = nullptr;
+            (void)hipGetLastError();
+            return true;   // no feedback channel: behave like mode 2
+        }
+        *c->h_half_flag = 0;
+    }
+    const uint32_t seen = __atomic_load_n(c->h_half_flag, __ATOMIC_RELAXED);
+    if (seen != c->half_flag_seen) {   // a launch since the last look held mostly non-half data
+        c->half_flag_seen = seen;
+        c->half_backoff_len = c->half_backoff_len ? std::min(2 * c->half_backoff_len, 1024) : 16;
+        c->half_backoff = c->half_backoff_len;
+    }
+    if (c->half_backoff > 0) {
+        c->half_backoff--;
+        c->half_backoff_launches++;
+        return false;
+    }
+    return true;
 }
 
 // dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)

@@ -48,6 +48,8 @@ static enc_kernel_t pick_enc2(int vw, int mode)
     if constexpr (CS == CS_YCBCR) {
         if (mode == 5)   // composite luma -> code records (vw == 4 or 2 as for the records)
             return vw == 4 ? k_encode<CS, SUB, 4, 5> : k_encode<CS, SUB, 2, 5>;
+        if (mode == 6)   // the same + the half-input table
+            return vw == 4 ? k_encode<CS, SUB, 4, 6> : k_encode<CS, SUB, 2, 6>;
     }
     if (mode == LUT_THRESH_LDS)
         return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
@@ -125,9 +127,23 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
     // YCbCr without per-frame statistics (they need the luminance itself): the luminance code comes straight from the luma
     const bool ycode = cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
+    // ... and R', G', B' of binary16 inputs from the half-input table of this call's (sc, Lmax), when table + records fit the LDS
+    const float *half = nullptr;
+    if (ycode && c->half_mode != 0 && lds_bytes(c, true, cs_eff, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
+        if ((rc = half_table_for(c, sc, &half)))
+            return rc;
+        if (half && !half_policy(c))
+            half = nullptr;
+    }
     EncArgs a{};
     a.q = ycode ? c->q_y : c->q;
-    const size_t lds = lds_bytes(c, true, cs_eff, ycode);
+    a.half = half;
+    if (half) {
+        c->half_launches++;
+        a.half_flag = c->half_mode == 1 ? c->h_half_flag : nullptr;
+        a.half_seq = ++c->half_seq;   // (never the initial 0 of the feedback word for 2^32 launches)
+    }
+    const size_t lds = lds_bytes(c, true, cs_eff, ycode, half != nullptr);
     const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
     const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
@@ -150,10 +166,10 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
             a.aligned = 0;
     }
     a.q.cs = cs_eff;
-    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, ycode ? 5 : mode);
+    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, half ? 6 : ycode ? 5 : mode);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = grid_for(c, threads, a.g.totalTiles, 0, false, cs_eff == CS_YCBCR);
+    const int grid = grid_for(c, threads, a.g.totalTiles, 0, 0, half ? 2 : cs_eff == CS_YCBCR ? 1 : 0);
     hipStream_t s = launch_stream(c);
     if (stats) {
         // partial triples live in a context-owned scratch buffer; launches with statistics of one context share it, which is

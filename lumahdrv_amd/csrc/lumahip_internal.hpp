@@ -57,6 +57,21 @@ struct lumahip_ctx {
     lh::QuantDev q_y{};           // q with the composite records in place of the luminance records
     float *d_ytab = nullptr;
     bool use_ycbcr_tables = true; // lumahip_tune("ycbcr_tables", 0): per-pixel PQ evaluation as in round 2 (A/B, tests)
+    // YCbCr encode, binary16 inputs: device copies of the half-input table (luma_device.hpp half_lookup), one per (sc, Lmax) seen;
+    // d == nullptr records "not usable for this pair" (host_lut.cpp ycbcr_half_table_host).  lumahip_core.hip half_table_for
+    struct HalfTab {
+        float sc = 0.0f, Lmax = 0.0f;
+        float *d = nullptr;
+        unsigned long last_use = 0;
+    };
+    std::vector<HalfTab> half_tabs;
+    unsigned long half_clock = 0;
+    int half_mode = 1;            // lumahip_tune("half_table"): 0 = never, 1 = while the stream looks like binary16 data (half_policy), 2 = always
+    // feedback of the half-input kernels (EncArgs::half_flag): one word of pinned host memory the kernels write and nobody waits for
+    uint32_t *h_half_flag = nullptr;
+    uint32_t half_seq = 0, half_flag_seen = 0;
+    int half_backoff = 0, half_backoff_len = 0;      // launches left on the per-pixel kernels; length of the current back-off
+    unsigned long half_launches = 0, half_backoff_launches = 0;
     bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
     std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer
     float *d_lut = nullptr;
@@ -181,12 +196,14 @@ struct DisplayParams {
 };
 
 // ---- lumahip_launch.hip
-size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false);   // ycode: the composite-record encode kernels
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false, bool half = false);   // ycode: the composite-record encode kernels; half: + the half-input table
 int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
-int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers = 0, bool ycbcr = false);   // few_writers: 0 no, 1 yes, 2 yes with the colour planes in separate buffers
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers = 0, int ycbcr = 0);   // few_writers: 0 no, 1 yes, 2 yes with the colour planes in separate buffers; ycbcr: 0 no, 1 yes, 2 the half-input encode kernels
 // ---- lumahip_core.hip
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
+int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the device half-input table of (sc, the quantizer's Lmax), or nullptr: none
+bool half_policy(lumahip_ctx *c);                                  // this launch: the half-input kernel (true) or the per-pixel one
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
 hipStream_t launch_stream(lumahip_ctx *c);   // the context's stream, or the next lane of an unordered section

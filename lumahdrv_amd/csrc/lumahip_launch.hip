@@ -8,7 +8,7 @@ using namespace lh;
 
 namespace lhost {
 
-size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode)
+size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode, bool half)
 {
     const QuantDev &q = c->q;
     size_t b = 0;
@@ -27,6 +27,8 @@ size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode)
         if (cs_eff == CS_YCBCR && q.ytab)
             b += lut_b;                                          // y table of the YCbCr decode kernels
     }
+    if (encode_side && ycode && half)   // the half-input kernels: the table, and the small powf tables for their general path
+        return b + (size_t)lds_half_bytes() + sizeof(PowfTables);
     if (cs_eff == CS_YCBCR)
         b += sizeof(PowfTablesWide);
     return b;
@@ -58,7 +60,7 @@ int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves)
 // {1, 2, 4, 8, 20, 50 frames} x {Lu'v', YCbCr} x {encode, decode} with every setting interleaved in one process
 // (tools/launch_rules_sweep.py, profiles/r03_launch_rules.txt: before / after tables).  lumahip_tune "grid_enc" / "grid_dec"
 // (absolute) and "blocks_per_cu" (per CU, both directions) are measurement overrides.
-int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers, bool ycbcr)
+int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers, int ycbcr)
 {
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : 2048 / threads;
     const bool rule = c->blocks_per_cu == 0;
@@ -94,6 +96,13 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int fe
     // 1-2 % from 18 (encode from 18 4K frames on, decode from 40).
     if (ycbcr && rule && threads == 512)
         per_cu = total_tiles >= (dir == 0 ? 36000 : 80000) ? 18 : 12;
+    // The half-input YCbCr encode kernels (ycbcr == 2) are HBM-bound again, and ONE of their 1024-thread workgroups (~140 KiB
+    // of LDS) is resident per CU; every further one stages the 124 KiB table anew.  Short launches want exactly the resident
+    // set (720p x4: 16.2 us against 19.6 with 2 or more per CU; 1080p x1: 15.1 / 17.4; 4K x1: 28.6 / 30.4), long ones many small
+    // static shares as the other YCbCr kernels do (4K x20: 422 us with 12 per CU against 466 with 2; 8K x20: 1659 / 1790);
+    // profiles/r04_half_table_grid.txt, tools/half_grid_sweep.py.
+    if (ycbcr == 2 && rule && threads == 1024)
+        per_cu = total_tiles < 3000 ? 1 : total_tiles < 12000 ? 3 : 12;
     long g = (long)c->num_cu * per_cu;
     // Inside an unordered section every launch keeps the grid it would have alone: two lanes of 3 (encode) / 5 (decode)
     // workgroups per CU each measured best (profiles/r03_layout_lab.txt: encode 0.780 of the roofline against 0.751 ordered,

@@ -357,3 +357,27 @@ def test_ycbcr_stream_tables_equal_the_reference_arithmetic(L, oracle_mod):
         assert np.array_equal(yt.view(np.uint32), e.view(np.uint32)), (ptf, bits)
     # a table the composite cannot be built for (LINEAR-12: too many records) simply has none
     assert not capi.ycbcr_luma_index(L.build_lut(L.PTF_LINEAR, 12, 1e4, 0.005), 1e4)["ok"]
+
+
+def test_half_input_table_equals_the_reference_arithmetic(L, oracle_mod):
+    """The half-input table of the YCbCr encode kernels (host_lut.cpp ycbcr_half_table_host): entry i against the oracle's
+    PQenc(std::max(x * sc, 1e-10f)) (src/luma_quantizer.cpp:331-333, 491-494) for EVERY half x in +0 ... +inf, for the
+    preScalings / peaks the GPU suite encodes with; and the pairs it must refuse."""
+    from lumahdrv_amd import capi
+    lo = oracle_mod.lib()
+    halves = np.arange(capi.HALF_TABLE_LEN, dtype=np.uint16).view(np.float16).astype(np.float32)
+    assert halves[0] == 0.0 and np.isinf(halves[-1]) and np.all(np.isfinite(halves[:-1]))
+    for sc in (1.0, 20.0, 0.25, 3.0e30):
+        for mx in (1000.0, 1e4):
+            t = capi.ycbcr_half_table(sc, mx)
+            assert t is not None and t.size == capi.HALF_TABLE_LEN
+            with np.errstate(over="ignore"):
+                arg = np.maximum(halves * np.float32(sc), np.float32(1e-10))
+            exp = np.array([lo.lo_transform_pq(mx, float(v), 1) for v in arg], dtype=np.float32)
+            same = (t.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(t) & np.isnan(exp))
+            assert bool(np.all(same)), (sc, mx, int(np.argmin(same)))
+            ok = np.isnan(t) | ((t >= np.float32(7e-7)) & (t <= np.float32(2.0)))
+            assert bool(np.all(ok)) and np.isnan(t[-1])          # PQenc(inf) = NaN, everything else in the licensed range
+    for sc, mx in ((0.0, 1e4), (-1.0, 1e4), (float("inf"), 1e4), (float("nan"), 1e4), (1.0, 0.0), (1.0, -5.0), (1.0, float("nan")),
+                   (1.0, 1e-30)):
+        assert capi.ycbcr_half_table(sc, mx) is None, (sc, mx)
