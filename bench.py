@@ -94,12 +94,14 @@ def parse():
     return ap.parse_args()
 
 
+PACKED_RING = 6          # batches of packed LumaFrames the packed-layout decode leg cycles through (6 x 20 x 4K = 12 GB)
+
 WORKLOADS = {
     # name: (ptf, bits, cs, bitsC, maxLum, minLum, preScaling, profile, description, transform, kernel)
     "pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0, 2, "PQ 11-bit Lu'v' 8-bit chroma, profile 2 (4:2:0 16-bit)",
                  "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
     "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0, 2, "HDR10 recipe: PQ 10-bit YCbCr BT.2020 10-bit chroma, max/min 1000/0.01, preScaling 20",
-                   "RGB->PQ->Y'CbCr (8 glibc-exact powf per pixel: VALU-bound, not HBM-bound)",
+                   "RGB->PQ->Y'CbCr (binary16 inputs: R'G'B' from the half-input table in LDS, luminance code from the composite records; HBM-bound)",
                    "lh::k_encode<CS_YCBCR,4:2:0,VW=4,LDS threshold records>"),
     "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0, 2, "LOG 12-bit Lu'v' 8-bit chroma, profile 2",
                   "RGB->XYZ->Lu'v'", "lh::k_encode<CS_LUV,4:2:0,VW=4,LDS threshold records>"),
@@ -347,6 +349,49 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
         # encode batch i, decode batch i: dependent, so ordered on one stream
         trt = tm.run(lambda i: (enc(i), dec(i)), lanes=0)
         r["roundtrip_mpix_s"] = round(rate(trt["wall_median"]), 1)
+    if main and striped:
+        # The reference's decoder returns the PACKED LumaFrame (include/luma/luma_frame.h:84-87: channel c at buffer + c*h*w), not
+        # the three-buffer layout the legs above write: the same decode launches into packed frames, a ring of PACKED_RING
+        # batches (>> the 256 MB MALL), once in chunks of the pool (the fastest float chunks left) and once in a plain allocation.
+        pk = {}
+        # "pool_rotating": batch b's packed frames in a chunk of region group b mod 3, so that the launches in flight on the
+        # two lanes write different groups (profiles/r03_layout_lab.txt found 0.75 for that arrangement)
+        for how in ("pool_placed", "pool_rotating", "plain"):
+            ring = rot = None
+            if how == "pool_placed":
+                ring = pool.take_float(min(PACKED_RING, len(pool.float)))
+                if len(ring) < 3:
+                    pool.give_back(ring, [], [])
+                    continue
+            elif how == "pool_rotating":
+                if min(len(g) for g in pool.striped) < PACKED_RING // 3:
+                    continue
+                rot = pool.take_striped(PACKED_RING // 3)
+                ring = [rot[k % 3][k // 3] for k in range(PACKED_RING)]
+            plain = torch.empty(PACKED_RING * B * n3, dtype=torch.float32, device=dev) if how == "plain" else None
+            nring = len(ring) if ring is not None else PACKED_RING
+
+            def dec_packed(i, ring=ring, plain=plain, nring=nring):
+                o = ring[i % nring].data_ptr() if ring is not None else plain.data_ptr() + (i % nring) * B * n3 * 4
+                ctx.decode_frames_device_planar(ptrs(i % nbatch)[2], st, psz, B, w, h, profile, sc, [o + k * n1 * 4 for k in range(3)], n3)
+
+            tp = tm.run(dec_packed)
+            tpo = tm.run(dec_packed, lanes=0) if lanes else tp
+
+            def fr(ms):
+                return round(BYTES_PER_PIXEL * px_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            pk[how] = {"value": round(rate(tp["wall_median"]), 1), "value_ordered": round(rate(tpo["wall_median"]), 1),
+                       "kernel_ms": round(tp["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(tpo["dev_ms_median"] / K, 4),
+                       "frac_ordered": fr(tpo["dev_ms_median"] / K), "frac_overlapped": fr(tp["dev_ms_median"] / K), "batches_in_ring": nring}
+            if rot is not None:
+                pool.give_back([], [], [], rot)
+            elif ring is not None:
+                pool.give_back(ring, [], [])
+            del plain
+            torch.cuda.empty_cache()
+        pk["layout"] = "packed LumaFrame (include/luma/luma_frame.h:84-87), what LumaDecoder::decode() returns"
+        pk["unit"] = "Mpixels/s; frac = algorithmic bytes / kernel_ms / 8 TB/s"
+        r["decode_packed_layout"] = pk
 
     if rank == 0:
         # ---- roofline of the dominant kernel: hipEvents over the timed regions (median region / K), rank 0
@@ -367,9 +412,17 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             tr = None                                     # captured for a different launch size: not this launch's bytes
 
         def hbm_block(ms, ms_ordered, ms_iso, probe, traffic_key, kern):
-            achieved = BYTES_PER_PIXEL * px_step / (ms * 1e-3) / 1e9
+            # `achieved` / `frac` price the kernel's OWN average launch duration: K launches back to back on one stream
+            # (kernel_ms_ordered), which is what a rocprofv3 kernel trace of `--lanes 0` reports per launch
+            # (profiles/*_kernel_stats_ordered.csv).  The default timed region overlaps launches on `lanes` streams; its window / K
+            # is a throughput figure (it is what `value` is made of) and is reported as *_overlapped.
+            over = BYTES_PER_PIXEL * px_step / (ms * 1e-3) / 1e9
+            achieved = over if ms_ordered is None else BYTES_PER_PIXEL * px_step / (ms_ordered * 1e-3) / 1e9
             blk = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
+                   "frac": round(achieved / HBM_PEAK_GBS, 4),
+                   "frac_is": "algorithmic bytes / kernel_ms_ordered / peak" if ms_ordered is not None else "algorithmic bytes / kernel_ms / peak",
+                   "achieved_overlapped": round(over, 1), "frac_overlapped": round(over / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * px_step,
                    "kernel": kern, "kernel_ms": round(ms, 4),
                    "kernel_ms_is": ("hipEvent window over the K launches of a region / K; the launches overlap on %d streams "
                                     "(lumahip_begin_unordered)" % lanes) if lanes else "hipEvent window over K back-to-back launches / K",
@@ -394,8 +447,21 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                             float(np.median(diso)) if diso else None, dprobe_ms, "decode_hbm_bytes_per_launch", dkname)
         dec_blk["output_layout"] = r["decode_output_layout"]
         mix = load_profile(os.path.join(args.profile_dir, "valu_mix_latest.json"), name, px_step, sha)
-        if cs == 2:
-            # YCbCr: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
+        half = ctx.half_table_info(sc) if cs == 2 else None
+        if cs == 2 and half["used"] and half["table_launches"] > 0 and half["backoff_launches"] == 0:
+            # YCbCr encode on the half-input table (the synthetic stream, like every EXR frame of the reference, holds binary16
+            # values): three LDS gathers instead of six powf per pixel -- HBM-bound like the Lu'v' kernels.  Decode has no such
+            # table (its powf arguments depend on (Y', Cr) / (Y', Cb) pairs) and stays VALU-bound.
+            r["roofline"] = enc_blk
+            r["roofline"]["kernel"] = "lh::k_encode<CS_YCBCR,4:2:0,VW=4,LM=6: composite records + half-input table in LDS>"
+            r["roofline"]["half_input_table"] = half
+            if mix:
+                r["roofline"]["valu_instructions_per_pixel"] = mix.get("valu_per_pixel")
+                r["roofline"]["fp64_instructions_per_pixel"] = mix.get("fp64_per_pixel")
+            r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]
+            r["decode_roofline"] = {"bound": "valu", "hbm": dec_blk}
+        elif cs == 2:
+            # YCbCr without the table: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
             # issue cost measured by tools/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
             # conversions / compares / selects / min / max 4, transcendental 8); peak = every SIMD issuing every cycle.
             peak = N_SIMD * CLOCK_GHZ                                  # G SIMD-cycles / s
@@ -694,8 +760,8 @@ def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True
             return None
         nb = nbatches if nbatches else min(500 // B, max(1, int(50e9 // (B * n3 * 4))))   # default: the 500-frame stream (4K), input + decoded output
         stripe = with_output and args.decode_layout == "auto" and spc >= 1
-        n_float = nb * (2 if (with_output and not stripe) else 1)
-        n_y, n_uv, n_striped = -(-nb // ypc), -(-nb // uvpc), (-(-nb // spc) if stripe else 0)
+        n_float = nb * (2 if (with_output and not stripe) else 1) + (PACKED_RING if stripe else 0)   # + the packed-layout decode leg
+        n_y, n_uv, n_striped = -(-nb // ypc), -(-nb // uvpc), (-(-nb // spc) + PACKED_RING // 3 if stripe else 0)
         ctx = L.Context(local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
@@ -810,6 +876,7 @@ def main():
             "value_ordered": r.get("value_ordered"), "decode_mpix_s_ordered": r.get("decode_mpix_s_ordered"),
             "decode_mpix_s": r["decode_mpix_s"], "decode_output_layout": r["decode_output_layout"],
             "roundtrip_mpix_s": r["roundtrip_mpix_s"],
+            "decode_packed_layout": r.get("decode_packed_layout"),
             "kernel_source_sha": sha,
             "placement": dict({"mode": args.placement}, **(pool.stats if pool is not None else {})),
         }

@@ -99,8 +99,17 @@ def test_bench_contract_single_gpu():
     assert dr["traffic"] is None or abs(dr["traffic"] / dr["algorithmic_bytes_per_launch"] - 1) < 0.05
     assert rf["kernel_ms_ordered"] > 0 and r["value_ordered"] > 0 and r["lanes"] == 2
     assert r["ms_per_step_over_ranks"]["min"] <= r["ms_per_step_over_ranks"]["max"]
+    # round 4: roofline.frac is the ORDERED figure (one launch's own duration, what a rocprofv3 kernel trace of --lanes 0 gives);
+    # the window of the overlapped launches is reported beside it
+    bytes_ = rf["algorithmic_bytes_per_launch"]
+    assert abs(bytes_ / (rf["kernel_ms_ordered"] * 1e-3) / 1e9 / rf["peak"] - rf["frac"]) < 2e-3 and rf["frac_overlapped"] > 0
+    assert abs(bytes_ / (dr["kernel_ms_ordered"] * 1e-3) / 1e9 / dr["peak"] - dr["frac"]) < 2e-3
     if r["placement"].get("grouped"):
         assert r["value_placement_off"] > 0
+        # the reference's decoder returns the packed LumaFrame: that layout's decode rate, pool-placed and plainly allocated
+        pk = r["decode_packed_layout"]
+        for how in ("pool_placed", "plain"):
+            assert pk[how]["value"] > 0 and 0 < pk[how]["frac_ordered"] < 1 and pk[how]["kernel_ms_ordered"] > 0, pk
     hf = r["facade_hostfed"]
     assert "error" not in hf, hf
     assert hf["LumaEncoder_encode_pageable_frame"] > 100 and hf["lumahip_encode_frames_host_pageable"] > 100 and hf["runs"] == 3
@@ -177,3 +186,17 @@ def test_config5_full_size_stream(driver, oracle_mod, tmp_path):
         psz = [int(x.numel()) for x in t]
         want = int(b.frame_digests(t, psz, 1, torch.device("cpu"))[0].item()) & 0x7FFFFFFFFFFFFFFF
         assert dig[f] == want, "frame %d of the stream differs from the oracle" % f
+
+
+@pytest.mark.gpu
+def test_bench_config3_encode_is_hbm_bound():
+    """BASELINE configs[2] (HDR10 recipe, 4K): the synthetic stream holds binary16 values, as every EXR frame of the reference
+    does, so the encode launches run on the half-input table and the line prices them against HBM; decode stays VALU-bound."""
+    p = _bench("--steps", "3", "--warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-other-workloads",
+               "--no-facade-hostfed", "--no-placement-off", "--workload", "pq10_ycbcr")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] > 0.5 and r["value"] > 250000, (rf["frac"], r["value"])
+    assert rf["half_input_table"]["table_launches"] > 0 and rf["half_input_table"]["backoff_launches"] == 0
+    assert r["decode_roofline"]["bound"] == "valu"
