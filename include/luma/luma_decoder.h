@@ -1,5 +1,6 @@
 // luma_decoder.h -- LumaDecoder with the reference's interface (include/luma/luma_decoder.h:60-175 there)
-// for the hot path: LumaDecoder(file) / initialize / run / decode / getBuffer / getParams / getQuantizer.
+// for the hot path: LumaDecoderBase (constructor, seekToTime, getQuantizer, getReader, getFrame on the base, as there) and
+// LumaDecoder(file) / initialize / run / decode / getBuffer / getParams.
 //
 // decode() = run() (fetch the next frame's Y/U/V planes from the upstream stage) + ONE fused HIP kernel
 // (unpack + LUT / colour dequantize + 2x2 chroma replicate + inverse colour transform) into the decoder's
@@ -23,6 +24,43 @@ struct LumaDecoderParamsBase {
     float preScaling, minLum, maxLum;
 };
 
+// The reference's base class (include/luma/luma_decoder.h:81-104 there): constructor (inputFile, verbose), the pure
+// virtual initialize / run / decode, and -- non-virtual, on the base -- seekToTime, getQuantizer, getReader, getFrame,
+// initialized.  The reference's base owns an MkvInterface (m_reader); this one owns the upstream stage it stands for here, a
+// LumaPlaneSource (default: the raw plane stream reader), which answers the two questions the reference's callers put to
+// getReader() (lumaplay.cpp:200,443: getDuration / getFrameDuration).
+class LumaDecoderBase {
+public:
+    LumaDecoderBase(const char *inputFile = NULL, bool verbose = 0)
+        : m_initialized(false), m_input(inputFile), m_source(NULL), m_time(0.0f), m_firstFrame(false)
+    {
+        (void)verbose;
+    }
+    virtual ~LumaDecoderBase() {}
+    virtual bool initialize(const char *inputFile, bool verbose = 0) = 0;
+    virtual bool run() = 0;
+    void seekToTime(float tm, bool absolute = false);
+    virtual LumaFrame *decode() = 0;
+    LumaQuantizer *getQuantizer() { return &m_quant; }
+    LumaPlaneSource *getReader() { return m_source ? m_source : &m_rawReader; }
+    LumaFrame *getFrame() { return &m_frame; }
+    bool initialized() { return m_initialized; }
+
+    // ---- addition ----
+    void setSource(LumaPlaneSource *src) { m_source = src; }  // not owned; default: the raw plane stream reader
+
+protected:
+    virtual void beforeSeek() {}   // a decoder with frames in flight drops them here (LumaDecoder's pipelined mode)
+    bool m_initialized;
+    const char *m_input;
+    LumaQuantizer m_quant;
+    LumaFrame m_frame;
+    LumaPlaneSource *m_source;
+    LumaRawStreamReader m_rawReader;
+    float m_time;
+    bool m_firstFrame;             // frame 0 was fetched by initialize() and is what the next run() returns
+};
+
 struct LumaDecoderParams : LumaDecoderParamsBase {
     LumaDecoderParams() : ptfBitDepth(11), colorBitDepth(8), highBitDepth(true), stride(NULL), profile(2)
     {
@@ -31,26 +69,7 @@ struct LumaDecoderParams : LumaDecoderParamsBase {
     }
     unsigned int ptfBitDepth, colorBitDepth;
     bool highBitDepth;
-    const int *stride;
-    int profile, width[3], height[3];
-};
-
-class LumaDecoderBase {
-public:
-    LumaDecoderBase() : m_initialized(false), m_input(NULL) {}
-    virtual ~LumaDecoderBase() {}
-    virtual bool initialize(const char *inputFile, bool verbose = 0) = 0;
-    virtual bool run() = 0;
-    virtual LumaFrame *decode() = 0;
-    LumaQuantizer *getQuantizer() { return &m_quant; }
-    LumaFrame *getFrame() { return &m_frame; }
-    bool initialized() { return m_initialized; }
-
-protected:
-    bool m_initialized;
-    const char *m_input;
-    LumaQuantizer m_quant;
-    LumaFrame m_frame;
+    int *stride, profile, width[3], height[3];   // stride: the decoder's own copy of the three plane strides (bytes)
 };
 
 class LumaDecoder : public LumaDecoderBase {
@@ -63,18 +82,12 @@ public:
     bool initialize(const char *inputFile, bool verbose = 0);
     bool run();
     LumaFrame *decode();  // NULL at end of stream
-    void seekToTime(float tm, bool absolute = false);
 
     unsigned char **getBuffer() { return m_planePtrs; }
     LumaDecoderParams getParams() { return m_params; }
     void setParams(LumaDecoderParams params) { m_params = params; }
 
-    // the reference returns its MkvInterface here (luma_decoder.h:113 there; lumaplay.cpp:200,443 ask it for
-    // getDuration() / getFrameDuration()); this build's upstream stage is a LumaPlaneSource with the same two queries
-    LumaPlaneSource *getReader() { return m_source; }
-
     // ---- additions ----
-    void setSource(LumaPlaneSource *src) { m_source = src; }  // not owned; default: raw plane stream
     // Pipelined mode (opt-in): decode() reads and uploads the planes of frame i+1 and queues its kernel BEFORE it completes
     // frame i and returns it, so the download of a frame (12 B/pixel, the heavy direction here) runs under the next frame's
     // read, upload and kernel.  Same frames in the same order; the returned frame is valid until the next decode(), as always.
@@ -83,14 +96,14 @@ public:
     void setPipelined(bool on) { m_pipelined = on; }
     bool pipelined() const { return m_pipelined; }
 
+protected:
+    void beforeSeek() { dropInFlight(); }
+
 private:
     LumaDecoderParams m_params;
     const LumaPlanes *m_vpxFrame;
     unsigned char *m_planePtrs[3];
-    bool m_firstFrame;
-    LumaPlaneSource *m_source;
-    LumaRawStreamReader m_rawReader;
-    float m_time;
+    int m_stride[3];               // what m_params.stride points at
     bool pushNext();               // pipelined mode: read the next frame's planes and start it; false at the end of the stream
     void dropInFlight();
     LumaFrame m_frame2;            // pipelined mode: decoded frames alternate between m_frame and this one

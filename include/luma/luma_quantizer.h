@@ -1,8 +1,9 @@
 // luma_quantizer.h -- LumaQuantizer with the reference's public interface
 // (include/luma/luma_quantizer.h:89-126 there), implemented on the MI355X through the C ABI of
-// include/lumahip.h.  Everything that touches pixel values runs as HIP kernels -- including the per-value
-// quantize()/dequantize() members (one-element launches of the array kernels: API parity, not a fast path).
-// Only the construction of the transfer-function table stays on the host, as in the reference.
+// include/lumahip.h.  Everything that touches frames, planes or arrays runs as HIP kernels.  On the host, as in the
+// reference: the construction of the transfer-function table, and the per-value quantize() / dequantize() members
+// (scalar calls on the host copy of the table, ~tens of ns like the reference's -- a kernel launch per sample would
+// make any caller that loops over them a thousand times slower).
 #ifndef LUMA_HIP_QUANTIZER_H
 #define LUMA_HIP_QUANTIZER_H
 

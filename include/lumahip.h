@@ -141,6 +141,17 @@ int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float maxLum, float *out
 int lumahip_ycbcr_half_table_host(float sc, float maxLum, float *out, size_t cap);
 int lumahip_half_table_info(lumahip_ctx *ctx, float sc, int info[6]);
 
+/* Host-only (no GPU, no context): LumaQuantizer::quantize / dequantize for ONE value (src/luma_quantizer.cpp:215-264) on a
+ * table of lut_len = 2^bitdepth floats -- the reference's literal bisection + nearest-of-two for channel 0 (and for every
+ * channel of the RGB / XYZ colour spaces), clamp(floor(maxC*val + 0.5f), 0, maxC) resp. std::max(val/maxC, 1e-10f) for the
+ * colour channels, maxC = 2^bitdepthC - 1.  The reference's per-sample members cost ~50 ns and callers written against it may
+ * loop over them; the facade's LumaQuantizer::quantize / dequantize call these instead of launching a kernel per sample.
+ * Frames, planes and arrays are never processed this way: those entry points run the kernels. */
+int lumahip_quantize_value_host(const float *lut, size_t lut_len, int colorspace, unsigned bitdepthC, float val, unsigned ch,
+                                float *out);
+int lumahip_dequantize_value_host(const float *lut, size_t lut_len, int colorspace, unsigned bitdepthC, float val, unsigned ch,
+                                  float *out);
+
 /* introspection of the search index built for the current LUT (tests):
  * info[0] = mode (0 = literal bisection, table in LDS; 2 = literal bisection, table read from global memory
  *                 (bitdepth > 12); 3 = threshold records in LDS; 4 = threshold records in global memory),
@@ -394,8 +405,15 @@ void lumahip_multi_destroy(lumahip_multi *m);
 int lumahip_multi_shards(const lumahip_multi *m);
 lumahip_ctx *lumahip_multi_ctx(lumahip_multi *m, int shard);   /* the shard's context (owned by m) */
 const char *lumahip_multi_last_error(const lumahip_multi *m);
-/* 1 when the table reached the devices through RCCL, 0 when only one distinct device is in use (nothing to broadcast) */
+/* 1 when the last table reached the devices through RCCL; 0 when every shard's context took it from the host: only one
+ * distinct device is in use (nothing to broadcast), or librccl could not be loaded (nothing to broadcast with), or host
+ * copies were asked for.  lumahip_multi_transport_note says which, in words. */
 int lumahip_multi_used_rccl(const lumahip_multi *m);
+const char *lumahip_multi_transport_note(const lumahip_multi *m);
+/* How lumahip_multi_set_quantizer carries the table: 0 (default) = RCCL broadcast when the shards span several devices and
+ * librccl loads, host copies otherwise; 1 = always RCCL, also as a one-rank communicator on a single device (fails when
+ * librccl cannot be loaded); 2 = always host copies.  The devices end up with the same table either way. */
+int lumahip_multi_set_transport(lumahip_multi *m, int mode);
 int lumahip_shard_range(unsigned nframes, int shard, int nshards, unsigned *first, unsigned *count);
 /* same arguments as lumahip_set_quantizer; the table is uploaded to the first device and broadcast to the others */
 int lumahip_multi_set_quantizer(lumahip_multi *m, int ptf, unsigned bitdepth, int colorspace, unsigned bitdepthC,

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
     "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
@@ -31,7 +31,7 @@ SYMBOLS = [
     "lumahip_probe_decode_traffic_device",
     "lumahip_pool_create", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
     "lumahip_pool_stats_json", "lumahip_pool_find_groups",
-    "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl",
+    "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl", "lumahip_multi_set_transport", "lumahip_multi_transport_note",
     "lumahip_shard_range", "lumahip_multi_set_quantizer", "lumahip_multi_encode_frames_host", "lumahip_multi_decode_frames_host",
     "lumahip_multi_encode_frames_device", "lumahip_multi_decode_frames_device", "lumahip_multi_sync",
     "lumahip_time_launches", "lumahip_probe_encode_traffic_device", "lumahip_powf_probe_device", "lumahip_quantize_probe_device", "lumahip_ycbcr_luma_probe_device", "lumahip_host_register", "lumahip_host_unregister", "lumahip_malloc", "lumahip_free", "lumahip_memcpy_h2d", "lumahip_memcpy_d2h",
@@ -125,6 +125,8 @@ def lib():
     L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
     L.lumahip_ycbcr_half_table_host.argtypes = [f, f, vp, sz]
     L.lumahip_half_table_info.argtypes = [vp, f, C.POINTER(i)]
+    L.lumahip_quantize_value_host.argtypes = [vp, sz, i, u, f, u, C.POINTER(f)]
+    L.lumahip_dequantize_value_host.argtypes = [vp, sz, i, u, f, u, C.POINTER(f)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
     L.lumahip_decode_frame_host.argtypes = [vp, pp3, ip3, u, u, i, f, vp]
     L.lumahip_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
@@ -178,6 +180,9 @@ def lib():
     L.lumahip_multi_last_error.argtypes = [vp]
     L.lumahip_multi_last_error.restype = C.c_char_p
     L.lumahip_multi_used_rccl.argtypes = [vp]
+    L.lumahip_multi_set_transport.argtypes = [vp, i]
+    L.lumahip_multi_transport_note.argtypes = [vp]
+    L.lumahip_multi_transport_note.restype = C.c_char_p
     L.lumahip_shard_range.argtypes = [u, i, i, C.POINTER(u), C.POINTER(u)]
     L.lumahip_multi_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_multi_encode_frames_host.argtypes = [vp, pp3, u, u, u, f, i, pp3, ip3, C.POINTER(f)]
@@ -283,6 +288,17 @@ def ycbcr_ytab(lut: np.ndarray, max_lum: float) -> np.ndarray:
     if rc != OK:
         raise LumaHipError(rc, "lumahip_ycbcr_ytab_host failed")
     return out
+
+
+def quantize_value(lut: np.ndarray, cs: int, bitdepth_c: int, val: float, ch: int = 0, dequantize: bool = False) -> float:
+    """host-only: LumaQuantizer::quantize / dequantize for one value (include/lumahip.h lumahip_quantize_value_host)"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    out = C.c_float(0)
+    fn = lib().lumahip_dequantize_value_host if dequantize else lib().lumahip_quantize_value_host
+    rc = fn(lut.ctypes.data, lut.size, cs, bitdepth_c, val, ch, C.byref(out))
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_(de)quantize_value_host: bad argument")
+    return float(out.value)
 
 
 HALF_TABLE_LEN = 0x7C00 + 1
@@ -655,6 +671,13 @@ class Multi:
 
     def used_rccl(self) -> bool:
         return bool(self.L.lumahip_multi_used_rccl(self.h))
+
+    def set_transport(self, mode: int):
+        """0 auto (RCCL across several devices, host copies on one), 1 always RCCL, 2 always host copies"""
+        self._chk(self.L.lumahip_multi_set_transport(self.h, mode))
+
+    def transport_note(self) -> str:
+        return self.L.lumahip_multi_transport_note(self.h).decode()
 
     def ctx(self, shard: int) -> Context:
         """the shard's context as a (non-owning) Context"""

@@ -54,6 +54,7 @@ bool LumaBatchEncoder::initialize(const char *outputFile, const unsigned int w, 
 
     m_w = w;
     m_h = h;
+    m_planes.clear();   // plane buffers of an earlier initialize() belong to its geometry / profile
     const std::string how = "HIP / gfx950, " + std::to_string(shards()) + " shard(s), table over " +
                             (quantizerCameOverRccl() ? "RCCL" : "host copies");
     luma_detail::printBanner(m_params, outputFile, how.c_str());

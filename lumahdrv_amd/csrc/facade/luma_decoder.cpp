@@ -7,13 +7,12 @@
 #include "../../../include/lumahip.h"
 
 LumaDecoder::LumaDecoder(const char *inputFile, bool verbose)
-    : m_vpxFrame(NULL), m_firstFrame(false), m_source(NULL), m_time(0.0f), m_pushed(0), m_pipelined(false)
+    : LumaDecoderBase(inputFile, verbose), m_vpxFrame(NULL), m_pushed(0), m_pipelined(false)
 {
     m_planePtrs[0] = m_planePtrs[1] = m_planePtrs[2] = NULL;
-    if (inputFile != NULL) {
-        m_input = inputFile;
+    m_stride[0] = m_stride[1] = m_stride[2] = 0;
+    if (inputFile != NULL)
         initialize(inputFile, verbose);
-    }
 }
 
 LumaDecoder::~LumaDecoder()
@@ -127,7 +126,9 @@ bool LumaDecoder::initialize(const char *inputFile, bool verbose)
     m_firstFrame = true;
 
     m_params.highBitDepth = m_vpxFrame->highBitDepth;
-    m_params.stride = m_vpxFrame->stride;
+    for (int p = 0; p < 3; p++)
+        m_stride[p] = m_vpxFrame->stride[p];
+    m_params.stride = m_stride;
     m_params.profile = m_vpxFrame->profile();
     for (int p = 0; p < 3; p++) {
         m_params.width[p] = (int)m_vpxFrame->planeWidth(p);
@@ -179,14 +180,17 @@ LumaFrame *LumaDecoder::decode()
     return &m_frame;
 }
 
-void LumaDecoder::seekToTime(float tm, bool absolute)
+// include/luma/luma_decoder.h:89-92 of the reference: the base forwards to its reader.  Here the upstream stage seeks by
+// frame; the raw plane stream is constant-rate: time -> frame index at the stream's fps.
+void LumaDecoderBase::seekToTime(float tm, bool absolute)
 {
-    // the raw plane stream is constant-rate: time -> frame index at the stream's fps
-    dropInFlight();   // (pipelined mode: what was read ahead belongs to the old position)
+    beforeSeek();   // (pipelined mode: what was read ahead belongs to the old position)
     m_time = absolute ? tm : m_time + tm;
     if (m_time < 0.0f)
         m_time = 0.0f;
-    const float fps = (m_source == &m_rawReader && m_rawReader.fps() > 0.0f) ? m_rawReader.fps() : 25.0f;
-    m_source->seekToFrame((unsigned int)(m_time * fps));
+    LumaPlaneSource *src = getReader();
+    const float fd = src->getFrameDuration();
+    const float fps = fd > 0.0f ? 1.0f / fd : 25.0f;
+    src->seekToFrame((unsigned int)(m_time * fps));
     m_firstFrame = false;
 }

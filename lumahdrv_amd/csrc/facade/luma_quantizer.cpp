@@ -85,17 +85,18 @@ void LumaQuantizer::syncMapping()
         throw LumaException(lumahip_last_error(m_ctx));
 }
 
-// Per-value API of the reference (its own plane loops call these per sample; nothing in this library does).
-// Evaluated by the same GPU kernels as the array forms -- one-element launches: slow per call, but there is no
-// pixel arithmetic on the CPU anywhere in the product.  Use the frame-level calls (or
-// lumahip_quantize_array_host) for bulk work.
+// Per-value API of the reference (src/luma_quantizer.cpp:215-264; its own plane loops call these per sample, and so may code
+// written against it).  Evaluated on the host table m_mapping -- the one getMapping() hands out, so a table written through that
+// pointer is seen at once, as in the reference -- by the library's host-only scalar forms: a call costs what the reference's
+// does (tens of ns), not a kernel launch.  Bulk work belongs to the frame-level calls and lumahip_quantize_array_host, which
+// run the kernels; nothing in this library processes a frame through these two members.
 float LumaQuantizer::quantize(const float val, const unsigned int ch) const
 {
     if (!m_configured)
         throw LumaException("LumaQuantizer::quantize before setQuantizer");
     float out = 0.0f;
-    if (lumahip_quantize_array_host(m_ctx, &val, &out, 1, ch) != LUMAHIP_OK)
-        throw LumaException(lumahip_last_error(m_ctx));
+    if (lumahip_quantize_value_host(m_mapping.data(), m_mapping.size(), (int)m_colorSpace, m_bitdepthColor, val, ch, &out) != LUMAHIP_OK)
+        throw LumaException("LumaQuantizer::quantize: bad quantizer state");
     return out;
 }
 
@@ -104,8 +105,8 @@ float LumaQuantizer::dequantize(const float val, const unsigned int ch) const
     if (!m_configured)
         throw LumaException("LumaQuantizer::dequantize before setQuantizer");
     float out = 0.0f;
-    if (lumahip_dequantize_array_host(m_ctx, &val, &out, 1, ch) != LUMAHIP_OK)
-        throw LumaException(lumahip_last_error(m_ctx));
+    if (lumahip_dequantize_value_host(m_mapping.data(), m_mapping.size(), (int)m_colorSpace, m_bitdepthColor, val, ch, &out) != LUMAHIP_OK)
+        throw LumaException("LumaQuantizer::dequantize: bad quantizer state");
     return out;
 }
 

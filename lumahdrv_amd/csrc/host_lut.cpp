@@ -163,3 +163,44 @@ bool ycbcr_half_table_host(float sc, float Lmax, float *out)
 }
 
 }  // namespace lh
+
+// ---- LumaQuantizer::quantize / dequantize for ONE value (src/luma_quantizer.cpp:215-264), on the host.  The reference's are
+// ~50 ns scalar calls and code written against it may loop over them (its own plane loops do, src/luma_encoder.cpp:293); the
+// facade's per-value members come here instead of paying a kernel launch per sample.  Frames and arrays never do: those are
+// the kernels' job.  Same arithmetic as the reference: the literal bisection + nearest-of-two on the table, std::min / std::max
+// argument order, floor(maxC*v + 0.5f) for the colour channels.
+extern "C" int lumahip_quantize_value_host(const float *lut, size_t lut_len, int colorspace, unsigned bitdepthC, float val,
+                                           unsigned ch, float *out)
+{
+    if (!lut || !out || lut_len < 2 || lut_len > 65536 || bitdepthC < 1 || bitdepthC > 16)
+        return LUMAHIP_ERR_ARG;
+    if (ch == 0 || colorspace == LUMAHIP_CS_RGB || colorspace == LUMAHIP_CS_XYZ) {
+        *out = (float)lh::quantize_literal_host(val, lut, (int)lut_len - 1);
+    } else {
+        const unsigned maxC = (1u << bitdepthC) - 1;
+        float res = floorf(maxC * val + 0.5f);
+        res = std::max(0.0f, std::min((float)maxC, res));
+        *out = res;
+    }
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_dequantize_value_host(const float *lut, size_t lut_len, int colorspace, unsigned bitdepthC, float val,
+                                             unsigned ch, float *out)
+{
+    if (!lut || !out || lut_len < 2 || lut_len > 65536 || bitdepthC < 1 || bitdepthC > 16)
+        return LUMAHIP_ERR_ARG;
+    if (ch == 0 || colorspace == LUMAHIP_CS_RGB || colorspace == LUMAHIP_CS_XYZ) {
+        const unsigned maxVal = (unsigned)lut_len - 1;
+        if (val < 0)
+            *out = lut[0];
+        else if (val >= maxVal)
+            *out = lut[maxVal];
+        else
+            *out = lut[(val != val) ? maxVal : (unsigned)(int)val];   // (a NaN index is undefined in the reference; the array kernels answer the top entry too)
+    } else {
+        const unsigned maxC = (1u << bitdepthC) - 1;
+        *out = std::max(val / maxC, 1e-10f);
+    }
+    return LUMAHIP_OK;
+}

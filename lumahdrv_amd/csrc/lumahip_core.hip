@@ -164,6 +164,8 @@ extern "C" int lumahip_sync(lumahip_ctx *c)
         return LUMAHIP_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->lanes_active; i++)   // inside an unordered section: its lanes too (include/lumahip.h)
+        HIPCHK(c, hipStreamSynchronize(c->lane_stream[i]));
     return LUMAHIP_OK;
 }
 
@@ -224,6 +226,9 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
     if (!c || !key)
         return LUMAHIP_ERR_ARG;
     const std::string k(key);
+    // the keys that rebuild the device tables: not under frames pushed with the stream entry points (as lumahip_set_quantizer)
+    if ((k == "lds_table_max_kb" || k == "force_literal" || k == "ycbcr_tables") && c->es_head != c->es_tail)
+        return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push / lumahip_decode_stream_push are still in flight: pop them before '%s'", key);
     if (k == "block") {
         if (v == 0) {
             c->block_threads = 256;
@@ -736,9 +741,9 @@ bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nf
 }
 
 // rows and bytes per row of plane p as vpx_img_alloc lays it out (src/luma_encoder.cpp:121-128)
-hipStream_t launch_stream(lumahip_ctx *c)
+hipStream_t launch_stream(lumahip_ctx *c, bool lanes)
 {
-    if (c->lanes_active == 0)
+    if (!lanes || c->lanes_active == 0)
         return c->stream;
     return c->lane_stream[c->lane_next++ % (unsigned)c->lanes_active];
 }

@@ -110,7 +110,7 @@ static bool planes_are_separate_buffers(float *const rgb[3], size_t frame_stride
 
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                 unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
-                const DisplayParams &dp, int cs_eff)
+                const DisplayParams &dp, int cs_eff, bool lanes)
 {
     const bool have_rgb = rgb && rgb[0];
     if (!c || (!have_rgb && !dp.rgba) || (have_rgb && (!rgb[1] || !rgb[2])) || !planes || !stride || !pfs || nframes == 0)
@@ -177,7 +177,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     if (few_writers && have_rgb && planes_are_separate_buffers(rgb, frame_stride, nframes, w, h))
         few_writers = 2;
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, few_writers, cs_eff == CS_YCBCR);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, launch_stream(c), a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, launch_stream(c, lanes), a);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }
@@ -230,7 +230,7 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
         return LUMAHIP_ERR_ARG;
     const size_t n = (size_t)w * h;
     float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, DisplayParams(), c->q.cs);
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, DisplayParams(), c->q.cs, true);
 }
 
 extern "C" int lumahip_decode_frames_device_planar(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
@@ -241,7 +241,7 @@ extern "C" int lumahip_decode_frames_device_planar(lumahip_ctx *c, const unsigne
         return LUMAHIP_ERR_ARG;
     if (!rgb_planes || !rgb_planes[0])
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
-    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_planes, frame_stride, DisplayParams(), c->q.cs);
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, rgb_planes, frame_stride, DisplayParams(), c->q.cs, true);
 }
 
 // Traffic probe: the loads and stores of k_decode<., 4:2:0, VW=4> for 16-bit planes with NO arithmetic (an xor keeps every

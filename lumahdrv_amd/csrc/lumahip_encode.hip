@@ -105,7 +105,7 @@ namespace lhost {
 
 int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
                               unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
-                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff)
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes)
 {
     if (!c || !rgb || !rgb[0] || !rgb[1] || !rgb[2] || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
@@ -170,7 +170,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 0, 0, half ? 2 : cs_eff == CS_YCBCR ? 1 : 0);
-    hipStream_t s = launch_stream(c);
+    hipStream_t s = launch_stream(c, lanes);
     if (stats) {
         // partial triples live in a context-owned scratch buffer; launches with statistics of one context share it, which is
         // safe on one stream (in order) and is why an unordered section with statistics keeps to its first lane
@@ -183,7 +183,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
             HIPCHK(c, hipMalloc(&c->d_stats_part, need));
             c->d_stats_part_cap = need;
         }
-        if (c->lanes_active)
+        if (lanes && c->lanes_active)
             s = c->lane_stream[0];
         a.stats = c->d_stats_part;
         const int np = (int)nframes * STATS_SLOTS;
@@ -209,7 +209,7 @@ extern "C" int lumahip_encode_frames_device(lumahip_ctx *c, const float *rgb, si
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     const size_t n = (size_t)w * h;
     const float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
-    return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+    return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs, true);
 }
 
 extern "C" int lumahip_encode_frames_device_planar(lumahip_ctx *c, const float *const rgb_planes[3], size_t frame_stride,
@@ -219,7 +219,7 @@ extern "C" int lumahip_encode_frames_device_planar(lumahip_ctx *c, const float *
 {
     if (!c)
         return LUMAHIP_ERR_ARG;
-    return encode_frames_device_impl(c, rgb_planes, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs);
+    return encode_frames_device_impl(c, rgb_planes, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs, true);
 }
 
 extern "C" int lumahip_probe_encode_traffic_device(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes,

@@ -9,6 +9,24 @@
 using namespace lh;
 using namespace lhost;
 
+// The fused kernels on packed frames for the entry points of this file: always on c->stream (which the callers point at their
+// kernel stream), never on a lane of an open unordered section -- the uploads and downloads around them are ordered against
+// that stream's events (include/lumahip.h: only the four _device encode / decode entry points take part in a section).
+static int encode_packed(lumahip_ctx *c, const float *rgb, size_t frame_stride, unsigned nframes, unsigned w, unsigned h, float sc,
+                         int profile, unsigned char *const planes[3], const int stride[3], const size_t pfs[3], float *stats)
+{
+    const size_t n = (size_t)w * h;
+    const float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
+    return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs, false);
+}
+static int decode_packed(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
+                         unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride)
+{
+    const size_t n = (size_t)w * h;
+    float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, DisplayParams(), c->q.cs, false);
+}
+
 // ---- host <-> device transfers of the _host entry points --------------------------------------------------------
 // Caller memory is pageable unless the caller pinned it (hipHostMalloc, hipHostRegister / lumahip_host_register).
 // Pinned memory is handed to the copy engine directly (asynchronous, the fast path of the batched entry points).
@@ -42,7 +60,7 @@ struct lumahip_copy_pool {
     std::atomic<int> pending{0};
     std::atomic<bool> stop{false};
 
-    explicit lumahip_copy_pool(int n)
+    lumahip_copy_pool(int n, int spin_) : spin(spin_)   // (set before the workers exist: they read it without synchronisation)
     {
         jobs.resize(n);
         for (int i = 0; i < n; i++)
@@ -131,8 +149,7 @@ void lumahip_copy_pool_destroy(lumahip_copy_pool *p) { delete p; }
 static void staged_copy(lumahip_ctx *c, unsigned char *dst, size_t dp, const unsigned char *src, size_t sp, size_t width, size_t rows)
 {
     if (c->copy_threads > 0 && !c->copy_pool) {
-        c->copy_pool = new lumahip_copy_pool(c->copy_threads);
-        c->copy_pool->spin = c->copy_spin;
+        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin);
     }
     if (c->copy_pool)
         c->copy_pool->copy(dst, dp, src, sp, width, rows);
@@ -212,6 +229,35 @@ static int d2h_flush(lumahip_ctx *c)
     return LUMAHIP_OK;
 }
 
+// Error paths: download chunks that are still pending point into the CALLER's memory (st.out).  A call that fails must not
+// leave them behind -- a later flush, or the ring coming round, would copy into buffers the caller may have freed by then.
+// d2h_drop waits for the DMA of every such chunk (all of them, or those with one tag: 0 = the plain calls, sequence number + 1 =
+// one pushed frame, so that a failing plain call leaves the chunks of frames pushed earlier alone) and forgets it without copying; DnGuard does that on every exit of a scope that has not been told the downloads were completed or handed over.
+static void d2h_drop(lumahip_ctx *c, bool all, unsigned tag)
+{
+    for (auto &st : c->stage_dn)
+        if (st.h && st.pending && (all || st.tag == tag)) {
+            if (st.ev)
+                (void)hipEventSynchronize(st.ev);
+            st.pending = false;
+            st.out = nullptr;
+        }
+}
+struct DnGuard {
+    lumahip_ctx *c;
+    bool all;
+    unsigned tag;
+    bool armed = true;
+    ~DnGuard()
+    {
+        if (!armed)
+            return;
+        if (c->s_d2h)
+            (void)hipStreamSynchronize(c->s_d2h);
+        d2h_drop(c, all, tag);
+    }
+};
+
 // The pipelined encode paths queue a whole frame's planes for download and go back to staging the next upload; that only
 // works while the ring of download chunks holds the frame (five chunks of 8 MiB for a 4K frame's 25 MB, eight are there).
 // The planes of an 8K frame are 99.5 MB: thirteen such chunks -- the ring came round to chunks of the SAME frame, the host sat
@@ -240,7 +286,7 @@ static int d2h_flush_upto(lumahip_ctx *c, unsigned seq)
 {
     for (int i = 0; i < lumahip_ctx::N_STAGE_DN; i++) {
         lumahip_ctx::Stage &st = c->stage_dn[(c->dn_next + i) % lumahip_ctx::N_STAGE_DN];
-        if (st.h && st.pending && (int)(st.tag - seq) <= 0)
+        if (st.h && st.pending && (int)(st.tag - (seq + 1)) <= 0)   // (tags are sequence number + 1; 0 = a chunk of a plain call: always due)
             if (int rc = stage_dn_ready(c, st))
                 return rc;
     }
@@ -519,6 +565,7 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
             return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));   // the bands run on the pipeline streams: after everything queued so far
         hipStream_t saved = c->stream;
+        DnGuard dn_guard{c, false, 0};   // a failing exit below drops the download chunks still pointing at the caller's planes
         auto fetch = [&](int k) -> int {              // planes rows of band k, after its kernel
             const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             HIPCHK(c, hipStreamWaitEvent(c->s_d2h, c->band_kern[k], 0));
@@ -556,6 +603,8 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
             rc = fetch(nb - 1);
         if (int r = d2h_flush(c))   // the chunks still in flight (also after an error: nothing may stay pending)
             rc = rc ? rc : r;
+        else
+            dn_guard.armed = false;
         c->stream = saved;
         HIPCHK(c, hipStreamSynchronize(c->s_h2d));
         HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -640,6 +689,7 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
             return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipStream_t saved = c->stream;
+        DnGuard dn_guard{c, false, 0};   // a failing exit below drops the download chunks still pointing at the caller's planes
         auto fetch = [&](int k) -> int {              // float rows of band k, after its kernel
             const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             const size_t roff = (size_t)r0 * w;
@@ -677,6 +727,8 @@ static int decode_frame_host_impl(lumahip_ctx *c, const unsigned char *const pla
             rc = fetch(nb - 1);
         if (int r = d2h_flush(c))   // the chunks still in flight (also after an error: nothing may stay pending)
             rc = rc ? rc : r;
+        else
+            dn_guard.armed = false;
         c->stream = saved;
         HIPCHK(c, hipStreamSynchronize(c->s_h2d));
         HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -781,6 +833,7 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
     if ((rc = dn_chunks_for(c, L.total)))
         return rc;
     hipStream_t saved = c->stream;
+    DnGuard dn_guard{c, false, 0};   // a failing exit drops the download chunks still pointing at the caller's buffers
     const size_t pfs[3] = {0, 0, 0};
     // Frame i's upload and kernel are queued BEFORE frame i-1's planes are fetched.
     auto fetch = [&](unsigned i) -> int {
@@ -811,7 +864,7 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         (void)hipEventRecord(sl.h2d, c->s_h2d);
         (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
         c->stream = c->s_kern;
-        rc = lumahip_encode_frames_device(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+        rc = encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
         c->stream = saved;
         if (rc)
             break;
@@ -823,6 +876,8 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
         rc = fetch(nframes - 1);
     if (int r = d2h_flush(c))   // (also after an error: nothing may stay pending)
         rc = rc ? rc : r;
+    else
+        dn_guard.armed = false;
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));
@@ -856,8 +911,9 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
         return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_decode_stream_push are in flight: pop them first");
     if (c->es_head - c->es_tail >= 2)
         return fail(c, LUMAHIP_ERR_STATE, "two frames are in flight already: lumahip_encode_stream_pop the oldest first");
-    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile))
-        return fail(c, LUMAHIP_ERR_STATE, "frame geometry changed while a frame is in flight: pop it first");
+    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile || stride[0] != c->es_stride[0] ||
+                                     stride[1] != c->es_stride[1] || stride[2] != c->es_stride[2]))
+        return fail(c, LUMAHIP_ERR_STATE, "frame geometry (size, profile or plane strides) changed while a frame is in flight: pop it first");
     HIPCHK(c, hipSetDevice(c->device));
     PlaneLayout L;
     plane_layout(L, w, h, profile, stride);
@@ -882,6 +938,7 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
         (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
     }
     c->up_ramp = 0;
+    DnGuard dn_guard{c, false, seq + 1};   // until the frame counts as pushed, a failure drops the download chunks queued for it
     const bool pinned_in = host_range_is_pinned(rgb, nfl * sizeof(float));
     if ((rc = xfer_h2d(c, sl.d_frame, rgb, nfl * sizeof(float), c->s_h2d)))
         return rc;
@@ -889,7 +946,7 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
     hipStream_t saved = c->stream;
     c->stream = c->s_kern;
-    rc = lumahip_encode_frames_device(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+    rc = encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
     c->stream = saved;
     if (rc)
         return rc;
@@ -897,7 +954,7 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     // the planes come down behind the kernel; pageable ones are emptied out of the staging chunks by the pop (or earlier,
     // when the ring comes round)
     (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
-    c->d2h_tag = seq;
+    c->d2h_tag = seq + 1;   // (0 = not a pushed frame)
     for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++)
         rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->s_d2h, true);
     c->d2h_tag = 0;
@@ -911,8 +968,12 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     c->es_h = h;
     c->es_profile = profile;
     c->es_sc = sc;
+    c->es_total = L.total;
+    for (int p = 0; p < 3; p++)
+        c->es_stride[p] = stride[p];
     c->es_dir = 0;
     c->es_head = seq + 1;
+    dn_guard.armed = false;   // the pop completes them
     return LUMAHIP_OK;
 }
 
@@ -955,8 +1016,9 @@ extern "C" int lumahip_decode_stream_push(lumahip_ctx *c, const unsigned char *c
         return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push are in flight: pop them first");
     if (c->es_head - c->es_tail >= 2)
         return fail(c, LUMAHIP_ERR_STATE, "two frames are in flight already: lumahip_decode_stream_pop the oldest first");
-    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile))
-        return fail(c, LUMAHIP_ERR_STATE, "frame geometry changed while a frame is in flight: pop it first");
+    if (c->es_head != c->es_tail && (w != c->es_w || h != c->es_h || profile != c->es_profile || stride[0] != c->es_stride[0] ||
+                                     stride[1] != c->es_stride[1] || stride[2] != c->es_stride[2]))
+        return fail(c, LUMAHIP_ERR_STATE, "frame geometry (size, profile or plane strides) changed while a frame is in flight: pop it first");
     HIPCHK(c, hipSetDevice(c->device));
     PlaneLayout L;
     plane_layout(L, w, h, profile, stride);
@@ -975,6 +1037,7 @@ extern "C" int lumahip_decode_stream_push(lumahip_ctx *c, const unsigned char *c
         (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);   // its floats downloaded
     }
     c->up_ramp = 0;
+    DnGuard dn_guard{c, false, seq + 1};   // until the frame counts as pushed, a failure drops the download chunks queued for it
     bool pinned_in = true;
     for (int p = 0; p < 3 && rc == LUMAHIP_OK; p++) {
         pinned_in = pinned_in && host_range_is_pinned(planes[p], (size_t)(L.rows[p] - 1) * stride[p] + L.row_bytes[p]);
@@ -986,13 +1049,13 @@ extern "C" int lumahip_decode_stream_push(lumahip_ctx *c, const unsigned char *c
     (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
     hipStream_t saved = c->stream;
     c->stream = c->s_kern;
-    rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
+    rc = decode_packed(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
     c->stream = saved;
     if (rc)
         return rc;
     (void)hipEventRecord(sl.kern, c->s_kern);
     (void)hipStreamWaitEvent(c->s_d2h, sl.kern, 0);
-    c->d2h_tag = seq;
+    c->d2h_tag = seq + 1;   // (0 = not a pushed frame)
     rc = xfer_d2h_deferred(c, rgb_out, sl.d_frame, nfl * sizeof(float), c->s_d2h);
     c->d2h_tag = 0;
     if (rc)
@@ -1004,8 +1067,12 @@ extern "C" int lumahip_decode_stream_push(lumahip_ctx *c, const unsigned char *c
     c->es_h = h;
     c->es_profile = profile;
     c->es_sc = sc;
+    c->es_total = L.total;
+    for (int p = 0; p < 3; p++)
+        c->es_stride[p] = stride[p];
     c->es_dir = 1;
     c->es_head = seq + 1;
+    dn_guard.armed = false;   // the pop completes them
     return LUMAHIP_OK;
 }
 
@@ -1051,6 +1118,7 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
     if ((rc = pipe_prepare(c, nfl * sizeof(float), L.total, nframes)))
         return rc;
     hipStream_t saved = c->stream;
+    DnGuard dn_guard{c, false, 0};   // a failing exit drops the download chunks still pointing at the caller's buffers
     const size_t pfs[3] = {0, 0, 0};
     auto fetch = [&](unsigned i) -> int {  // as in lumahip_encode_frames_host: frame i-1 is fetched after frame i is queued
         lumahip_ctx::Slot &sl = c->slot[i % 3];
@@ -1075,7 +1143,7 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
         (void)hipEventRecord(sl.h2d, c->s_h2d);
         (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
         c->stream = c->s_kern;
-        rc = lumahip_decode_frames_device(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
+        rc = decode_packed(c, dp, stride, pfs, 1, w, h, profile, sc, sl.d_frame, nfl);
         c->stream = saved;
         if (rc)
             break;
@@ -1087,6 +1155,8 @@ extern "C" int lumahip_decode_frames_host(lumahip_ctx *c, const unsigned char *c
         rc = fetch(nframes - 1);
     if (int r = d2h_flush(c))   // (also after an error: nothing may stay pending)
         rc = rc ? rc : r;
+    else
+        dn_guard.armed = false;
     c->stream = saved;
     HIPCHK(c, hipStreamSynchronize(c->s_h2d));
     HIPCHK(c, hipStreamSynchronize(c->s_kern));

@@ -130,6 +130,8 @@ struct lumahip_ctx {
     unsigned es_w = 0, es_h = 0;
     int es_profile = 0;
     float es_sc = 1.0f;
+    size_t es_total = 0;           // plane bytes and strides of the frames in flight (a push with other strides is refused)
+    int es_stride[3] = {0, 0, 0};
     float *h_es_stats = nullptr;   // pinned, 3 floats per slot
     unsigned d2h_tag = 0;          // tag given to download chunks queued now
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
@@ -206,7 +208,7 @@ int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the
 bool half_policy(lumahip_ctx *c);                                  // this launch: the half-input kernel (true) or the per-pixel one
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
-hipStream_t launch_stream(lumahip_ctx *c);   // the context's stream, or the next lane of an unordered section
+hipStream_t launch_stream(lumahip_ctx *c, bool lanes);   // the context's stream, or -- for the entry points that take part in unordered sections -- the next lane of an open one
 void plane_dims(unsigned w, unsigned h, int profile, int p, int &rows, int &row_bytes);
 // rgb: the three colour-plane base pointers of the float frames (nullptr: no float frames in this call)
 int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned nframes, const float *const rgb[3],
@@ -217,10 +219,13 @@ int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned n
 // rgb[c]: base of colour plane c; plane c of frame f at rgb[c] + f*frame_stride floats
 int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
                               unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
-                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff);
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes = false);
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                 unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
-                const DisplayParams &dp, int cs_eff);
+                const DisplayParams &dp, int cs_eff, bool lanes = false);
+// lanes: the call is one of the four _device encode / decode entry points and goes to a lane of an open unordered section;
+// every other caller (the _host entry points with their own upload / kernel / download streams, the stream push / pop, the
+// display decode) stays on c->stream whether a section is open or not, as include/lumahip.h promises
 int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsigned ch, bool quant);
 
 // ---- lumahip_misc.hip

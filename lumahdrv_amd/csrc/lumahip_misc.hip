@@ -143,6 +143,8 @@ extern "C" int lumahip_time_launches(lumahip_ctx *c, int dir, int iters, const f
 {
     if (!c || iters <= 0 || !avg_ms)
         return fail(c, LUMAHIP_ERR_ARG, "bad argument");
+    if (c->lanes_active)
+        return fail(c, LUMAHIP_ERR_STATE, "lumahip_time_launches brackets the context's stream: close the unordered section first");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ev;
     HIPCHK(c, ev.create());

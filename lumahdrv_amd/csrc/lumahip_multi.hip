@@ -36,10 +36,14 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     std::string why;
 
+    bool tried = false, ok = false;
+
+    // one attempt per process: a library that cannot be opened, or lacks an entry point, stays unusable (and unloaded)
     bool load()
     {
-        if (lib)
-            return true;
+        if (tried)
+            return ok;
+        tried = true;
         const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char *n : names) {
             lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -57,8 +61,16 @@ struct Rccl {
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast) {
             why = "librccl.so lacks ncclCommInitAll / ncclBroadcast / ncclGroupStart / ncclGroupEnd";
+            CommInitAll = nullptr;
+            CommDestroy = nullptr;
+            GroupStart = GroupEnd = nullptr;
+            Broadcast = nullptr;
+            GetErrorString = nullptr;
+            dlclose(lib);
+            lib = nullptr;
             return false;
         }
+        ok = true;
         return true;
     }
 };
@@ -78,6 +90,8 @@ struct lumahip_multi {
     std::vector<uint32_t *> bbuf;         // broadcast buffer per distinct device
     size_t bbuf_words = 0;
     bool used_rccl = false;
+    int transport = 0;                    // lumahip_multi_set_transport: 0 auto, 1 RCCL always, 2 host copies always
+    std::string note;                     // why the last table travelled the way it did
     std::string err;
 };
 
@@ -190,6 +204,18 @@ extern "C" const char *lumahip_multi_last_error(const lumahip_multi *m) { return
 
 extern "C" int lumahip_multi_used_rccl(const lumahip_multi *m) { return (m && m->used_rccl) ? 1 : 0; }
 
+extern "C" int lumahip_multi_set_transport(lumahip_multi *m, int mode)
+{
+    if (!m)
+        return LUMAHIP_ERR_ARG;
+    if (mode < 0 || mode > 2)
+        return mfail(m, LUMAHIP_ERR_ARG, "transport must be 0 (auto), 1 (RCCL) or 2 (host copies)");
+    m->transport = mode;
+    return LUMAHIP_OK;
+}
+
+extern "C" const char *lumahip_multi_transport_note(const lumahip_multi *m) { return m ? m->note.c_str() : ""; }
+
 // communicators, broadcast streams and buffers, created once per handle (the table may be replaced many times)
 static int ensure_comms(lumahip_multi *m, size_t words)
 {
@@ -226,6 +252,28 @@ extern "C" int lumahip_multi_set_quantizer(lumahip_multi *m, int ptf, unsigned b
         return LUMAHIP_ERR_ARG;
     if (!lut || bitdepth < 1 || bitdepth > 16 || n != ((size_t)1 << bitdepth))
         return mfail(m, LUMAHIP_ERR_ARG, "LUT must hold 2^bitdepth floats, bitdepth 1..16");
+    // How the table reaches the devices.  Several distinct devices: one RCCL broadcast from the first (below).  One distinct
+    // device (any number of shards on it), or an RCCL that cannot be loaded: there is nothing to broadcast / nothing to
+    // broadcast with -- every shard's context takes the table from the host, and lumahip_multi_used_rccl reports 0.
+    // lumahip_multi_set_transport(m, 1) insists on RCCL (a one-rank communicator on a single device; fails without RCCL),
+    // (m, 2) never uses it.
+    bool direct = m->transport == 2 || (m->transport == 0 && m->udev.size() == 1);
+    if (!direct && m->transport == 0 && !g_rccl.load()) {
+        direct = true;
+        m->note = "RCCL could not be loaded (" + g_rccl.why + "): the table went to every device from the host";
+    } else {
+        m->note = direct ? "one distinct device (or host copies requested): the table went to every shard from the host"
+                         : "RCCL broadcast from the first device";
+    }
+    if (direct) {
+        m->used_rccl = false;
+        for (size_t s = 0; s < m->ctx.size(); s++) {
+            const int rc = lumahip_set_quantizer(m->ctx[s], ptf, bitdepth, cs, bitdepthC, maxLum, minLum, lut, n);
+            if (rc != LUMAHIP_OK)
+                return mfail(m, rc, "shard %zu (device %d): %s", s, m->dev[s], lumahip_last_error(m->ctx[s]));
+        }
+        return LUMAHIP_OK;
+    }
     const size_t words = PARAM_WORDS + n;
     int rc = ensure_comms(m, words);
     if (rc)

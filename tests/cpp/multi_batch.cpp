@@ -103,6 +103,17 @@ int main(int argc, char **argv)
     for (const Case &cs : cases) {
         lumahip_multi *m = nullptr;
         CHECK(lumahip_multi_create(&m, cs.devices.data(), (int)cs.devices.size()) == LUMAHIP_OK, "multi_create (%s)", cs.name);
+        // the default transport: RCCL exactly when the shards span several devices (host copies on one device) ...
+        CHECK(lumahip_multi_set_quantizer(m, LUMAHIP_PTF_PQ, 11, LUMAHIP_CS_LUV, 8, 1e4f, 0.005f, lut.data(), lut.size()) == LUMAHIP_OK,
+              "%s", lumahip_multi_last_error(m));
+        {
+            bool several = false;
+            for (int d : cs.devices)
+                several = several || d != cs.devices[0];
+            CHECK(lumahip_multi_used_rccl(m) == (several ? 1 : 0), "default transport (%s): %s", cs.name, lumahip_multi_transport_note(m));
+        }
+        // ... and the same table through RCCL on request (a one-rank communicator when there is one device): what follows runs on it
+        CHECK(lumahip_multi_set_transport(m, 1) == LUMAHIP_OK && lumahip_multi_set_transport(m, 7) != LUMAHIP_OK, "set_transport");
         CHECK(lumahip_multi_set_quantizer(m, LUMAHIP_PTF_PQ, 11, LUMAHIP_CS_LUV, 8, 1e4f, 0.005f, lut.data(), lut.size()) == LUMAHIP_OK,
               "%s", lumahip_multi_last_error(m));
         CHECK(lumahip_multi_used_rccl(m) == 1, "the table did not travel over RCCL (%s)", cs.name);
@@ -208,7 +219,8 @@ int main(int argc, char **argv)
         enc.setParams(p);
         const int dv[3] = {0, 0, 0};
         enc.initialize(path, w, h, false, ndev > 1 ? NULL : dv, ndev > 1 ? 0 : 3);
-        CHECK(enc.quantizerCameOverRccl(), "LumaBatchEncoder: table not broadcast with RCCL");
+        // several devices: RCCL broadcast; three shards on the one device of this box: nothing to broadcast, host copies
+        CHECK(enc.quantizerCameOverRccl() == (ndev > 1), "LumaBatchEncoder: table transport (RCCL exactly when several devices are in use)");
         std::vector<LumaFrame *> ptrs;
         for (auto &f : frames)
             ptrs.push_back(f.get());

@@ -301,6 +301,15 @@ def test_pipelined_encoder_writes_the_same_stream(tmp_path, w, h, frames, cs, bi
     assert "OK pipelined decode: %d frames identical" % frames in r.stdout
 
 
+def test_many_shard_host_path_randomized_stress(tmp_path):
+    """tests/cpp/multi_stress.cpp: 200 iterations of random frame sizes / counts / profiles / strides / pinned-or-pageable buffers
+    through 8 logical shards (8 host threads, 8 contexts, 8 copy-thread pools) on ONE GPU, the quantizer replaced every 16
+    iterations: planes and decoded floats byte-identical to a single context."""
+    exe = _build_cpp(str(tmp_path), "multi_stress")
+    r = subprocess.run([exe, "200", "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK multi_stress: 200 iterations, 8 shards" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_many_gpu_layer_through_ctypes_against_the_oracle(oracle_mod):
     import torch
     import lumahdrv_amd as L
@@ -312,7 +321,11 @@ def test_many_gpu_layer_through_ctypes_against_the_oracle(oracle_mod):
     assert m.shards == len(devices)
     cfg = (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01)
     m.set_quantizer(*cfg, L.build_lut(L.PTF_PQ, 10, 1000.0, 0.01))
-    assert m.used_rccl()
+    assert m.used_rccl() == (ndev > 1), m.transport_note()     # one distinct device: nothing to broadcast, host copies
+    if ndev == 1:
+        m.set_transport(1)                                      # ... and through a one-rank RCCL communicator on request
+        m.set_quantizer(*cfg, L.build_lut(L.PTF_PQ, 10, 1000.0, 0.01))
+        assert m.used_rccl()
     orc = o.Oracle(*cfg)
     frames = [o.synth_frame(128, 64, 9, i) for i in range(7)]
     planes, st, means = m.encode_frames(frames, 20.0, 2)
@@ -402,3 +415,80 @@ def test_ycbcr_stream_tables_do_not_change_a_bit(oracle_mod, profile):
     got = [res[1][0][p][:psz[p]].reshape(hs[p], st[p]) for p in range(3)]
     assert all(np.array_equal(a, b) for a, b in zip(got, e))
     assert np.array_equal(res[1][1][:n3].reshape(3, h, w).view(np.uint32), orc.decode(e, st, w, h, sc, profile).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_scalar_host_forms_equal_the_array_kernels(oracle_mod):
+    """LumaQuantizer::quantize / dequantize per value on the host (lumahip_quantize_value_host, the facade's per-value members)
+    against the array kernels (lumahip_quantize_array_host) on the same inputs, every configuration, both kinds of channel."""
+    import lumahdrv_amd as L
+    from lumahdrv_amd import capi
+    from tests.golden.make_golden import CONFIGS
+    rng = np.random.default_rng(77)
+    special = np.array([0.0, -0.0, 1e-45, 1e-10, 1e-4, 1.0, 0.5, 0.4999999, 65504.0, 1e4, 1e8, 3e38, np.inf, -np.inf, np.nan, -1.0,
+                        -1e-30], dtype=np.float32)
+    for name, cfg in CONFIGS.items():
+        ptf, bits, cs, bitsC, mx, mn = cfg
+        q = L.LumaQuantizer()
+        q.setQuantizer(*cfg)
+        lut = q.getMapping()
+        v = np.concatenate([special, np.exp(rng.uniform(np.log(1e-6), np.log(1e5), 3000)).astype(np.float32),
+                            lut[rng.integers(0, lut.size, 500)], rng.uniform(-0.1, 1.1, 500).astype(np.float32)])
+        for ch in (0, 1):
+            arr = q.ctx.quantize_array(v, ch)
+            sca = np.array([capi.quantize_value(lut, cs, bitsC, float(x), ch) for x in v], dtype=np.float32)
+            assert np.array_equal(arr, sca), (name, ch, v[arr != sca][:5])
+            codes = np.concatenate([np.arange(-3, (1 << (bits if ch == 0 else bitsC)) + 3, dtype=np.float32)[:5000],
+                                    np.array([0.5, 1.999, np.nan, np.inf, -np.inf], dtype=np.float32)])
+            arr = q.ctx.dequantize_array(codes, ch)
+            sca = np.array([capi.quantize_value(lut, cs, bitsC, float(x), ch, dequantize=True) for x in codes], dtype=np.float32)
+            assert np.array_equal(arr.view(np.uint32), sca.view(np.uint32)) , (name, ch)
+
+
+@pytest.mark.gpu
+def test_sync_and_host_calls_inside_an_unordered_section(oracle_mod):
+    """lumahip_sync inside an open section waits for the section's lanes (results are read right after it, with the section
+    still open), and entry points other than the four _device encode / decode calls -- here the host entry points with their
+    own upload / kernel / download streams, and the stream push / pop -- keep to their own streams inside a section: a host call
+    between two lane launches reads its frame after it is uploaded and returns the right planes."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    cfg = (L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005)
+    lut = L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5])
+    c = L.Context(0)                      # its own stream: nothing but lumahip_sync orders the host reads below
+    c.set_quantizer(*cfg, lut)
+    orc = o.Oracle(*cfg)
+    w, h, B, NB, profile = 1280, 720, 4, 6, 2
+    n3 = 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, profile)
+    psz = [hs[p] * st[p] for p in range(3)]
+    d_src = c.malloc(NB * B * n3 * 4)
+    d_pl = [c.malloc(NB * B * psz[p]) for p in range(3)]
+    c.synth_frames_device(d_src, n3, NB * B, w, h, 9, 0)
+    c.sync()
+    hostf = o.synth_frame(w, h, 9, 1000)
+    exp_host, _, _ = orc.encode(hostf.copy(), 1.0, profile)
+    for rep in range(3):
+        for p in range(3):
+            c.h2d(d_pl[p], np.zeros(NB * B * psz[p], dtype=np.uint8))
+        c.begin_unordered(2)
+        for b in range(NB):
+            c.encode_frames_device(d_src + b * B * n3 * 4, n3, B, w, h, 1.0, profile, [d_pl[p] + b * B * psz[p] for p in range(3)], st, psz)
+            if b == 2:
+                got, _, _ = c.encode_frame(hostf, 1.0, profile)            # a host call in the middle of the section
+                for p in range(3):
+                    assert np.array_equal(got[p], exp_host[p]), (rep, p)
+        c.sync()                                                           # section still open
+        planes = [np.empty(NB * B * psz[p], dtype=np.uint8) for p in range(3)]
+        for p in range(3):
+            rc = c.L.lumahip_memcpy_d2h(c.h, planes[p].ctypes.data, d_pl[p], planes[p].nbytes)
+            assert rc == 0
+        c.end_unordered()
+        for f in (0, B * NB // 2, B * NB - 1):
+            e, _, _ = orc.encode(o.synth_frame(w, h, 9, f), 1.0, profile)
+            for p in range(3):
+                assert np.array_equal(planes[p][f * psz[p]:(f + 1) * psz[p]].reshape(hs[p], st[p]), e[p]), (rep, f, p)
+    c.free(d_src)
+    for p in d_pl:
+        c.free(p)
+    c.close()

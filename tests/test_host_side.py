@@ -207,6 +207,23 @@ def test_integration_examples_compile_against_the_reference(tmp_path):
         assert "lumahip_" in (out / f).read_text() or "lumahip_" in (out / f.replace(".cpp", ".h")).read_text()
 
 
+def test_decoder_base_class_usage_compiles_against_both_trees():
+    """tests/cpp/decoder_base_usage.cpp holds a LumaDecoderBase* and uses only what the reference documents on the base class
+    (constructor (inputFile, verbose), seekToTime, getQuantizer, getReader, getFrame, initialized; LumaDecoderParams::stride as
+    int *): it must compile unchanged against include/luma/ of this repo and -- in the build container -- against the
+    reference's headers (include/luma/luma_decoder.h:81-120 there)."""
+    src = os.path.join(ROOT, "tests", "cpp", "decoder_base_usage.cpp")
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include", "luma"), src], check=True)
+    ref = "/root/reference"
+    vpx = os.path.join(ROOT, "oracle", "_ref", "vpx_hdr")
+    if not os.path.isdir(os.path.join(ref, "src")):
+        return
+    if not os.path.isdir(os.path.join(vpx, "vpx")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_planes"], check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-I" + os.path.join(ref, "include", "luma"), "-I" + os.path.join(ref, "lib", "ebml"),
+                    "-I" + os.path.join(ref, "lib", "matroska"), "-I" + os.path.join(vpx, "vpx"), "-I" + vpx, src], check=True)
+
+
 def test_lumaenc_option_handling_equals_the_reference_parser(tmp_path):
     """tools/lumaenc's option handling (tools/luma_cli.h) against the reference's own ArgParser (src/arg_parser.cpp compiled
     unmodified behind lumaenc's option table: oracle/_ref/ref_argparser_tool, build container only) on the same command
@@ -381,3 +398,32 @@ def test_half_input_table_equals_the_reference_arithmetic(L, oracle_mod):
     for sc, mx in ((0.0, 1e4), (-1.0, 1e4), (float("inf"), 1e4), (float("nan"), 1e4), (1.0, 0.0), (1.0, -5.0), (1.0, float("nan")),
                    (1.0, 1e-30)):
         assert capi.ycbcr_half_table(sc, mx) is None, (sc, mx)
+
+
+def test_scalar_quantize_dequantize_equal_the_reference_fixture(L, golden_dir):
+    """LumaQuantizer::quantize / dequantize for one value on the host (lumahip_quantize_value_host, what the C++ facade's
+    per-value members call): every value of tests/golden/ref_quantize.npz -- produced by the reference's own compiled
+    LumaQuantizer (src/luma_quantizer.cpp:215-264), NaN / +-inf / -0 / denormals and out-of-range codes included -- for all
+    eight configurations, both channels.  No GPU."""
+    from lumahdrv_amd import capi
+    from tests.golden.make_golden import CONFIGS
+    g = np.load(os.path.join(golden_dir, "ref_quantize.npz"))
+    luts = np.load(os.path.join(golden_dir, "ref_luts.npz"))
+    for name, cfg in CONFIGS.items():
+        ptf, bits, cs, bitsC, mx, mn = cfg
+        lut = luts[name] if name in luts else L.build_lut(ptf, bits, mx, mn)
+        assert lut.size == 1 << bits
+        for ch in (0, 1):
+            vin = g["%s_in%d" % (name, ch)]
+            got = np.array([capi.quantize_value(lut, cs, bitsC, float(v), ch) for v in vin], dtype=np.float32)
+            assert np.array_equal(got.astype(np.uint16), g["%s_q%d" % (name, ch)]) and np.all(got == np.floor(got)), (name, ch)
+        codes = np.arange(-2, 2 ** bits + 2, dtype=np.float32)
+        dq0 = np.array([capi.quantize_value(lut, cs, bitsC, float(v), 0, dequantize=True) for v in codes], dtype=np.float32)
+        assert np.array_equal(dq0.view(np.uint32), g[name + "_dq0"].view(np.uint32)), name
+        dq1 = np.array([capi.quantize_value(lut, cs, bitsC, float(v), 1, dequantize=True) for v in range(2 ** bitsC)], dtype=np.float32)
+        assert np.array_equal(dq1.view(np.uint32), g[name + "_dq1"].view(np.uint32)), name
+    # bad arguments are refused, not read
+    import ctypes as C
+    out = C.c_float(0)
+    assert capi.lib().lumahip_quantize_value_host(None, 8, 0, 8, 1.0, 0, C.byref(out)) == capi.ERR_ARG
+    assert capi.lib().lumahip_dequantize_value_host(lut.ctypes.data, 1, 0, 8, 1.0, 0, C.byref(out)) == capi.ERR_ARG

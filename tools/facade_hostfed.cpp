@@ -170,12 +170,34 @@ int main(int argc, char **argv)
             (void)lumahip_host_unregister(ctx, f->buffer);
         for (auto &v : pl)
             (void)lumahip_host_unregister(ctx, v.data());
+        // LumaQuantizer::quantize / dequantize per value (src/luma_quantizer.cpp:215-264): scalar host calls, as in the reference
+        double q_ns = 0.0, dq_ns = 0.0;
+        {
+            LumaQuantizer *q = enc.getQuantizer();
+            const int m = 2000000;
+            float acc = 0.0f, v = 0.003f;
+            t0 = now();
+            for (int i = 0; i < m; i++) {
+                acc += q->quantize(v, 0) + q->quantize(v * 1e-4f, 1);
+                v = v * 1.00001f + 1e-6f;
+                if (v > 9000.0f)
+                    v = 0.003f;
+            }
+            q_ns = (now() - t0) / (2.0 * m) * 1e9;
+            t0 = now();
+            for (int i = 0; i < m; i++)
+                acc += q->dequantize((float)(i & 2047), 0) + q->dequantize((float)(i & 255), 1);
+            dq_ns = (now() - t0) / (2.0 * m) * 1e9;
+            if (acc == 12345.0f)
+                std::fprintf(stderr, "%g\n", acc);   // keeps the loops alive
+        }
         std::printf("{\"width\": %u, \"height\": %u, \"frames\": %d, \"unit\": \"Mpixels/s\", "
+                    "\"LumaQuantizer_quantize_ns_per_call\": %.1f, \"LumaQuantizer_dequantize_ns_per_call\": %.1f, "
                     "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_frame\": %.1f, "
                     "\"LumaEncoder_encode_registered_frame\": %.1f, "
                     "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
                     "\"decode_frame_host_pageable\": %.1f, \"decode_stream_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
-                    w, h, n, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
+                    w, h, n, q_ns, dq_ns, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;
