@@ -79,7 +79,8 @@ int lumahip_sync(lumahip_ctx *ctx);
  * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "band_taper" (each band's rows in
  * per cent of the previous band's, 10..100, default 70: the last band is small, so little is left to do once the upload ends), "ycbcr_tables" (0: the
  * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables),
- * "half_table" (0 / 1 / 2: when the YCbCr encode kernels use the half-input table, see lumahip_ycbcr_half_table_host).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
+ * "half_table" (0 / 1 / 2: when the YCbCr encode kernels use the half-input table, see lumahip_ycbcr_half_table_host),
+ * "numa" / "numa_node" (NUMA placement of the staging rings and copy threads, see lumahip_numa_info).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
  * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
  * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_BAND_TAPER, LUMAHIP_YCBCR_TABLES, LUMAHIP_HALF_TABLE set the
  * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
@@ -352,6 +353,21 @@ int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
 int lumahip_free(lumahip_ctx *ctx, void *dev_ptr);
 int lumahip_memcpy_h2d(lumahip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int lumahip_memcpy_d2h(lumahip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- NUMA placement of the host side ------------------------------------------------------------------------------------
+ * On a multi-socket host the context's pinned staging rings are allocated on the NUMA node of its GPU and its copy threads are
+ * pinned to that node's CPUs (within the CPUs the process may use); lumahip_multi_* does the same for each shard's thread.
+ * What this replaces is single-threaded (the loop at lumaenc.cpp:205-243 of the reference), so there is no reference
+ * behaviour to keep.  lumahip_tune("numa", 0) switches it off; ("numa_node", N) pretends the GPU sits on node N (A/B
+ * measurements, profiles/r04_numa.txt); both take effect for what is allocated / started afterwards.
+ * lumahip_numa_info: info = {node of the GPU or -1 (one-node host, unknown, switched off), number of CPUs the threads are pinned
+ * to, the first of them}.  lumahip_numa_pin_current_thread pins the CALLING thread the same way -- for callers that drive one
+ * context per thread themselves.  lumahip_numa_plan_host is host-only (no GPU, no context): node and CPUs for a PCI bus id from
+ * a sysfs tree (NULL = /sys), optionally restricted to a cpulist such as "0-63,128-191"; *ncpus = 0 when there is nothing to do. */
+int lumahip_numa_info(lumahip_ctx *ctx, int info[3]);
+int lumahip_numa_pin_current_thread(lumahip_ctx *ctx);
+int lumahip_numa_plan_host(const char *sysfs_root, const char *pci_bus_id, const char *allowed_cpulist, int *node, int *cpus, int cap,
+                           int *ncpus);
 
 /* ---- HBM chunk pool: WHERE device-resident streams live ------------------------------------------------------------
  * On MI355X device memory falls into a few groups of multi-GiB regions, and a launch runs up to 15 % slower when the

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_numa_info", "lumahip_numa_pin_current_thread", "lumahip_numa_plan_host", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
     "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
@@ -125,6 +125,9 @@ def lib():
     L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
     L.lumahip_ycbcr_half_table_host.argtypes = [f, f, vp, sz]
     L.lumahip_half_table_info.argtypes = [vp, f, C.POINTER(i)]
+    L.lumahip_numa_info.argtypes = [vp, C.POINTER(i)]
+    L.lumahip_numa_pin_current_thread.argtypes = [vp]
+    L.lumahip_numa_plan_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(i), C.POINTER(i), i, C.POINTER(i)]
     L.lumahip_quantize_value_host.argtypes = [vp, sz, i, u, f, u, C.POINTER(f)]
     L.lumahip_dequantize_value_host.argtypes = [vp, sz, i, u, f, u, C.POINTER(f)]
     L.lumahip_encode_frame_host.argtypes = [vp, vp, u, u, f, i, pp3, ip3, C.POINTER(f), vp]
@@ -301,6 +304,17 @@ def quantize_value(lut: np.ndarray, cs: int, bitdepth_c: int, val: float, ch: in
     return float(out.value)
 
 
+def numa_plan(sysfs_root, pci_bus_id: str, allowed: str = ""):
+    """host-only: (node, [cpus]) the library would place the host side of a context on for the GPU at `pci_bus_id`"""
+    node, n = C.c_int(-1), C.c_int(0)
+    cpus = (C.c_int * 4096)()
+    rc = lib().lumahip_numa_plan_host(sysfs_root.encode() if sysfs_root else None, pci_bus_id.encode(), allowed.encode(), C.byref(node), cpus,
+                                      4096, C.byref(n))
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_numa_plan_host: bad argument")
+    return node.value, list(cpus[:min(n.value, 4096)])
+
+
 HALF_TABLE_LEN = 0x7C00 + 1
 
 
@@ -378,6 +392,11 @@ class Context:
         a = (C.c_int * 5)()
         self._chk(self.L.lumahip_quantizer_info(self.h, a))
         return dict(mode=a[0], mant_bits=a[1], buckets=a[2], shift=a[3], lds_bytes=a[4])
+
+    def numa_info(self):
+        a = (C.c_int * 3)()
+        self._chk(self.L.lumahip_numa_info(self.h, a))
+        return dict(node=a[0], cpus=a[1], first_cpu=a[2])
 
     def half_table_info(self, sc: float):
         a = (C.c_int * 6)()

@@ -68,7 +68,7 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
                                               {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_BAND_TAPER", "band_taper"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
-                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}, {"LUMAHIP_HALF_TABLE", "half_table"}};
+                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}, {"LUMAHIP_HALF_TABLE", "half_table"}, {"LUMAHIP_NUMA", "numa"}, {"LUMAHIP_NUMA_NODE", "numa_node"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
                 (void)lumahip_tune(c, k[1], atol(e));
@@ -264,6 +264,15 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->use_ycbcr_tables = v != 0;
         if (c->have_quant)
             return requantize(c);
+    } else if (k == "numa" || k == "numa_node") {
+        // takes effect for what is allocated / started from now on: set it before the first host call of a context
+        if (k == "numa")
+            c->numa_mode = v != 0;
+        else
+            c->numa_force_node = v >= 0 ? (int)std::min<long>(v, 1023) : -1;
+        c->numa_resolved = false;
+        lumahip_copy_pool_destroy(c->copy_pool);
+        c->copy_pool = nullptr;
     } else if (k == "half_table") {
         if (v < 0 || v > 2)
             return fail(c, LUMAHIP_ERR_ARG, "half_table must be 0 (off), 1 (while the stream is binary16 data) or 2 (always)");
@@ -672,6 +681,67 @@ extern "C" int lumahip_half_table_info(lumahip_ctx *c, float sc, int info[6])
         info[2] += t.d != nullptr;
     info[4] = (int)std::min<unsigned long>(c->half_launches, 0x7fffffffUL);
     info[5] = (int)std::min<unsigned long>(c->half_backoff_launches, 0x7fffffffUL);
+    return LUMAHIP_OK;
+}
+
+// The NUMA node of the context's GPU and the CPUs of that node this process may run on.  Nothing on a one-node host.
+void numa_resolve(lumahip_ctx *c)
+{
+    if (c->numa_resolved)
+        return;
+    c->numa_resolved = true;
+    c->numa_node = -1;
+    c->numa_cpus.clear();
+    if (!c->numa_mode)
+        return;
+    FILE *two = fopen("/sys/devices/system/node/node1/cpulist", "r");   // a second node exists?
+    if (!two)
+        return;
+    fclose(two);
+    int node = c->numa_force_node;
+    if (node < 0) {
+        int v = -1;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeHostNumaId, c->device) == hipSuccess && v >= 0)
+            node = v;
+        else
+            (void)hipGetLastError();
+    }
+    if (node < 0) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) == hipSuccess)
+            node = numa_node_of_pci("/sys", bus);
+        else
+            (void)hipGetLastError();
+    }
+    if (node < 0)
+        return;
+    std::vector<int> cpus;
+    if (!numa_cpus_of_node("/sys", node, numa_allowed_cpus(), cpus))
+        return;   // (e.g. a cpuset that excludes the whole node: leave the threads where the scheduler puts them)
+    c->numa_node = node;
+    c->numa_cpus = cpus;
+}
+
+extern "C" int lumahip_numa_info(lumahip_ctx *c, int info[3])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    numa_resolve(c);
+    info[0] = c->numa_node;
+    info[1] = (int)c->numa_cpus.size();
+    info[2] = c->numa_cpus.empty() ? -1 : c->numa_cpus[0];
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_numa_pin_current_thread(lumahip_ctx *c)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    numa_resolve(c);
+    if (c->numa_node >= 0 && !numa_pin_thread(pthread_self(), c->numa_cpus))
+        return fail(c, LUMAHIP_ERR_STATE, "pthread_setaffinity_np refused the CPUs of NUMA node %d", c->numa_node);
     return LUMAHIP_OK;
 }
 

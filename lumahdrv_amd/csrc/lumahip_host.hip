@@ -60,11 +60,16 @@ struct lumahip_copy_pool {
     std::atomic<int> pending{0};
     std::atomic<bool> stop{false};
 
-    lumahip_copy_pool(int n, int spin_) : spin(spin_)   // (set before the workers exist: they read it without synchronisation)
+    // cpus: the CPUs of the GPU's NUMA node (empty: no placement) -- the workers write the pinned staging chunks, which live on
+    // that node, and read them back out of it
+    lumahip_copy_pool(int n, int spin_, const std::vector<int> &cpus) : spin(spin_)   // (spin is set before the workers exist: they read it without synchronisation)
     {
         jobs.resize(n);
-        for (int i = 0; i < n; i++)
+        for (int i = 0; i < n; i++) {
             workers.emplace_back([this, i]() { loop(i); });
+            if (!cpus.empty())
+                (void)lh::numa_pin_thread(workers.back().native_handle(), cpus);
+        }
     }
     ~lumahip_copy_pool()
     {
@@ -149,7 +154,8 @@ void lumahip_copy_pool_destroy(lumahip_copy_pool *p) { delete p; }
 static void staged_copy(lumahip_ctx *c, unsigned char *dst, size_t dp, const unsigned char *src, size_t sp, size_t width, size_t rows)
 {
     if (c->copy_threads > 0 && !c->copy_pool) {
-        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin);
+        numa_resolve(c);
+        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin, c->numa_cpus);
     }
     if (c->copy_pool)
         c->copy_pool->copy(dst, dp, src, sp, width, rows);
@@ -178,7 +184,19 @@ static bool host_range_is_pinned(const void *p, size_t bytes)
 static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st, size_t bytes = XFER_CHUNK)
 {
     if (!st.h) {
-        HIPCHK(c, hipHostMalloc((void **)&st.h, bytes, hipHostMallocDefault));
+        // on the GPU's NUMA node: the calling thread's memory policy says where, hipHostMallocNumaUser makes the runtime follow it
+        numa_resolve(c);
+        bool placed = false;
+        if (c->numa_node >= 0 && numa_prefer_node(c->numa_node)) {
+            placed = hipHostMalloc((void **)&st.h, bytes, hipHostMallocNumaUser) == hipSuccess;
+            (void)numa_prefer_node(-1);
+            if (!placed) {
+                st.h = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        if (!placed)
+            HIPCHK(c, hipHostMalloc((void **)&st.h, bytes, hipHostMallocDefault));
         if (!st.ev)
             HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
     }

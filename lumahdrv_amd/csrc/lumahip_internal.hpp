@@ -26,6 +26,7 @@
 #include "luma_kernels.hpp"
 #include "host_lut.hpp"
 #include "lut_index.hpp"
+#include "numa_host.hpp"
 
 // Largest search table (encode: threshold records, decode: the luminance table) a workgroup stages in LDS; beyond it
 // the table is read from global memory (L2-resident).  gfx950 has 160 KiB of LDS per CU; tables beyond 53 KiB run as one
@@ -136,6 +137,13 @@ struct lumahip_ctx {
     unsigned d2h_tag = 0;          // tag given to download chunks queued now
     float *h_small = nullptr;  // pinned scratch for the few-float readbacks
     lumahip_copy_pool *copy_pool = nullptr;
+    // NUMA placement of the host side (numa_host.cpp; lumahip_core.hip numa_resolve): the node of this context's GPU and that
+    // node's CPUs.  The pinned staging rings are allocated on the node and the copy threads are pinned to its CPUs.
+    int numa_mode = 1;         // lumahip_tune("numa", 0): no placement, as before round 4
+    int numa_force_node = -1;  // lumahip_tune("numa_node", N): pretend the GPU sits on node N (A/B measurements: local against remote)
+    bool numa_resolved = false;
+    int numa_node = -1;        // -1: not a NUMA box / unknown / switched off
+    std::vector<int> numa_cpus;
     int copy_threads = 3;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)
     int copy_spin = 2000;      // lumahip_tune("copy_spin"): polls of an idle worker before it sleeps
 
@@ -205,7 +213,8 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int fe
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
 int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the device half-input table of (sc, the quantizer's Lmax), or nullptr: none
-bool half_policy(lumahip_ctx *c);                                  // this launch: the half-input kernel (true) or the per-pixel one
+bool half_policy(lumahip_ctx *c);
+void numa_resolve(lumahip_ctx *c);                                 // fills numa_node / numa_cpus once (cheap afterwards)                                  // this launch: the half-input kernel (true) or the per-pixel one
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
 hipStream_t launch_stream(lumahip_ctx *c, bool lanes);   // the context's stream, or -- for the entry points that take part in unordered sections -- the next lane of an open one

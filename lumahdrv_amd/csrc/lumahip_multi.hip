@@ -343,7 +343,10 @@ static int for_each_shard(lumahip_multi *m, unsigned nframes, F fn)
         (void)lumahip_shard_range(nframes, s, ns, &first, &count);
         if (count == 0)
             continue;
-        th.emplace_back([&, s, first, count]() { rcs[s] = fn(s, first, count); });
+        th.emplace_back([&, s, first, count]() {
+            (void)lumahip_numa_pin_current_thread(m->ctx[s]);   // this thread IS the shard's calling thread: next to its GPU (no-op on one-node hosts)
+            rcs[s] = fn(s, first, count);
+        });
     }
     for (auto &t : th)
         t.join();

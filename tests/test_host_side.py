@@ -427,3 +427,33 @@ def test_scalar_quantize_dequantize_equal_the_reference_fixture(L, golden_dir):
     out = C.c_float(0)
     assert capi.lib().lumahip_quantize_value_host(None, 8, 0, 8, 1.0, 0, C.byref(out)) == capi.ERR_ARG
     assert capi.lib().lumahip_dequantize_value_host(lut.ctypes.data, 1, 0, 8, 1.0, 0, C.byref(out)) == capi.ERR_ARG
+
+
+def test_numa_plan_from_a_fabricated_sysfs_tree(tmp_path):
+    """lumahip_numa_plan_host: which NUMA node and which CPUs the host side of a context is placed on, derived from a sysfs
+    tree shaped like the GPU boxes' (two sockets, 64 cores x 2 threads each, GPUs on both) -- no GPU, no /sys of this machine."""
+    from lumahdrv_amd import capi
+    root = tmp_path / "sys"
+    for node, cl in ((0, "0-63,128-191\n"), (1, "64-127,192-255\n")):
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl)
+    for bus, node in (("0000:05:00.0", "0\n"), ("0000:85:00.0", "1\n"), ("0000:c5:00.0", "-1\n"), ("0001:0a:00.0", "7\n")):
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node)
+    r = str(root)
+    n0 = list(range(0, 64)) + list(range(128, 192))
+    n1 = list(range(64, 128)) + list(range(192, 256))
+    assert capi.numa_plan(r, "0000:05:00.0") == (0, n0)
+    assert capi.numa_plan(r, "0000:85:00.0") == (1, n1)
+    assert capi.numa_plan(r, "0000:85:00.0".upper()) == (1, n1) and capi.numa_plan(r, "85:00.0") == (1, n1)   # as hipDeviceGetPCIBusId may print it
+    assert capi.numa_plan(r, "0000:85:00.0", "0-7,64-71,200") == (1, list(range(64, 72)) + [200])              # a cpuset: only what the process may use
+    assert capi.numa_plan(r, "0000:85:00.0", "0-7") == (1, [])                                               # the cpuset excludes the node: no pinning
+    assert capi.numa_plan(r, "0000:c5:00.0") == (-1, [])                                                     # the kernel does not know: nothing
+    assert capi.numa_plan(r, "0000:ff:00.0") == (-1, [])                                                     # no such device
+    assert capi.numa_plan(r, "0001:0a:00.0") == (7, [])                                                      # a node without a cpulist
+    with pytest.raises(capi.LumaHipError):
+        capi.numa_plan(r, "0000:85:00.0", "3-1")
+    with pytest.raises(capi.LumaHipError):
+        capi.numa_plan(r, "0000:85:00.0", "a,b")
