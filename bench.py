@@ -462,7 +462,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             r["decode_roofline"] = {"bound": "valu", "hbm": dec_blk}
         elif cs == 2:
             # YCbCr without the table: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
-            # issue cost measured by tools/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
+            # issue cost measured by tools/bench/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
             # conversions / compares / selects / min / max 4, transcendental 8); peak = every SIMD issuing every cycle.
             peak = N_SIMD * CLOCK_GHZ                                  # G SIMD-cycles / s
             common = {k: enc_blk[k] for k in ("kernel", "kernel_ms", "kernel_ms_is", "kernel_ms_ordered", "kernel_ms_isolated_launch",

@@ -104,22 +104,6 @@ int lumahip_set_quantizer(lumahip_ctx *ctx, int ptf, unsigned bitdepth, int colo
  * reference reads out of bounds there), LUMAHIP_ERR_STATE if a data table cannot be read. */
 int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, float *lut_out, size_t lut_len);
 
-/* Host-only (no GPU, no context): the threshold records lumahip_set_quantizer builds for a monotone finite table
- * (lumahdrv_amd/csrc/lut_index.hpp): quantize(v) = (rec[clamp(bits(v) >> shift, kmin, kmin+nbuckets-1) - kmin]
- * + (bits(v) & (2^shift - 1))) >> shift for every float that is not a sign-set NaN (those give maxVal).
- * info = {ok, mantissa bits of the key, shift, kmin, nbuckets}; ok = 0 when the table does not qualify (NaNs,
- * decreasing or duplicate entries, too many records) and the kernels run the literal bisection instead.
- * rec_out (nullable, rec_cap entries) receives the records. */
-int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
-
-/* Host-only (no GPU, no context): the two per-stream tables of the YCbCr kernels, built with the host libm as the reference
- * would evaluate them per pixel.  (1) The threshold records -- same format and lookup as lumahip_thresh_index_host, for
- * arguments t >= +0 or NaN -- of the composite function  t -> quantize(PQdec(t / 255), 0)  with t = 219 y + 16, y the pixel's luma
- * (src/luma_quantizer.cpp:337, 496-500, 222-235), from which the encode kernels take a pixel's luminance code.
- * (2) out[i] = (255 PQenc(lut[i]) - 16) / 219 (src/luma_quantizer.cpp:447-448, 491-494), which the decode kernels read
- * instead of evaluating PQenc per pixel. */
-int lumahip_ycbcr_luma_index_host(const float *lut, size_t n, float maxLum, int info[5], uint32_t *rec_out, size_t rec_cap);
-int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float maxLum, float *out);
 
 /* Half-input table of the YCbCr encode kernels.  The reference's EXR reader hands the encoder binary16 values widened to float
  * (src/exr_interface.cpp:77-146 reads Imf::Rgba), and for such an input x the non-linear colour value
@@ -299,54 +283,12 @@ int lumahip_mean_luminance_reference_device(lumahip_ctx *ctx, const float *rgb_d
 int lumahip_quantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);
 int lumahip_dequantize_array_device(lumahip_ctx *ctx, const float *in_dev, float *out_dev, size_t n, unsigned ch);
 
-/* Synthetic benchmark input, generated on the device by the integer-only recipe of SURVEY.md 8(d)
- * (identical to the oracle's lo_synth_frame): frame index first_frame + f at dst_dev + f*frame_stride. */
-int lumahip_synth_frames_device(lumahip_ctx *ctx, float *dst_dev, size_t frame_stride, unsigned nframes,
-                                unsigned w, unsigned h, uint64_t seed, uint64_t first_frame);
-
-/* Timing helper for benchmarks: runs `iters` encode (dir=0) or decode (dir=1) launches of the same
- * arguments back to back on the context's stream between two hipEvents and returns the average
- * kernel-launch duration in milliseconds (events are recorded on the stream the kernels run on). */
-int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb_dev, size_t frame_stride,
-                          unsigned nframes, unsigned w, unsigned h, float sc, int profile,
-                          unsigned char *const planes_dev[3], const int stride[3],
-                          const size_t plane_frame_stride[3], float *avg_ms);
-
-/* Test probe: the luminance search exactly as the encode kernels instantiate it (four values per thread, the
- * context's search mode; nonneg != 0 selects the Lu'v' kernels' variant, which relies on every value being >= 0 or NaN)
- * over the n consecutive fp32 bit patterns first_bits, first_bits+1, ...: out_dev[i] = code.  n % 4 == 0.
- * Counterpart of LumaQuantizer::quantize(val, 0) (src/luma_quantizer.cpp:222-235). */
-int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg);
-
-/* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
- * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the
- * device function with the host libm exhaustively. */
-int lumahip_powf_probe_device(lumahip_ctx *ctx, float *out_dev, uint32_t first_bits, size_t n, float y, int regular);
-
-/* Test probe (YCbCr quantizers): out[i] = the luminance code of a pixel whose t = 219 y + 16 (y = its luma,
- * src/luma_quantizer.cpp:335-337) is the float with bit pattern first_bits + i.  direct = 0: through the composite threshold
- * records exactly as the encode kernels read them; direct = 1: the reference's arithmetic, PQdec(t / 255) then LumaQuantizer::quantize(., 0)
- * (src/luma_quantizer.cpp:337, 496-500, 222-235), evaluated on the device with the complete powf and IEEE division.
- * n % 4 == 0.  LUMAHIP_ERR_UNSUPPORTED when the table has no composite records. */
-int lumahip_ycbcr_luma_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int direct);
 
 /* Pin caller-owned host memory (hipHostRegister) so that the _host entry points DMA it at PCIe rate instead
  * of going through the runtime's pageable staging path.  Optional; unregister before freeing the memory. */
 int lumahip_host_register(lumahip_ctx *ctx, void *host_ptr, size_t bytes);
 int lumahip_host_unregister(lumahip_ctx *ctx, void *host_ptr);
 
-/* Benchmark probe: the loads and stores of the 4:2:0 16-bit encode kernel with no arithmetic in between (same
- * tile order, same access widths, non-temporal), `iters` launches, average milliseconds.  OVERWRITES the planes
- * with garbage.  What the memory system alone needs for the encode traffic mix on this device. */
-int lumahip_probe_encode_traffic_device(lumahip_ctx *ctx, const float *rgb_dev, size_t frame_stride, unsigned nframes,
-                                        unsigned w, unsigned h, unsigned char *const planes_dev[3], const int stride[3],
-                                        const size_t plane_frame_stride[3], int iters, float *avg_ms);
-
-/* The decode counterpart: the loads and stores of the 4:2:0 16-bit decode kernel (3 B read + 12 B written per pixel) with no
- * arithmetic.  OVERWRITES the frames with garbage.  Float frames as in lumahip_decode_frames_device_planar. */
-int lumahip_probe_decode_traffic_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
-                                        const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
-                                        float *const rgb_planes_dev[3], size_t frame_stride, int iters, float *avg_ms);
 
 /* ---- device memory helpers (for hosts without their own allocator, e.g. the C++ facade) -------- */
 int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
@@ -451,6 +393,77 @@ int lumahip_multi_decode_frames_device(lumahip_multi *m, const unsigned char *co
                                        const size_t plane_frame_stride[3], const unsigned *count, unsigned w, unsigned h,
                                        int profile, float sc, float *const *rgb_dev, size_t frame_stride);
 int lumahip_multi_sync(lumahip_multi *m);
+
+/* ==== EXPERIMENTAL: measurement and test hooks ===========================================================================
+ * Everything below exists for this repository's tests, bench.py and the tools under tools/bench/: probes that run parts of
+ * the kernels on synthetic bit patterns, host-only views of the tables the library builds, the synthetic-frame generator
+ * and a launch timer.  The library always exports them, but they are NOT part of the drop-in surface: nothing a caller of
+ * the reference needs is here, and they may change without a new LUMAHIP_ABI_VERSION.  Declared only when
+ * LUMAHIP_EXPERIMENTAL is defined before this header is included. */
+#ifdef LUMAHIP_EXPERIMENTAL
+
+/* Host-only (no GPU, no context): the threshold records lumahip_set_quantizer builds for a monotone finite table
+ * (lumahdrv_amd/csrc/lut_index.hpp): quantize(v) = (rec[clamp(bits(v) >> shift, kmin, kmin+nbuckets-1) - kmin]
+ * + (bits(v) & (2^shift - 1))) >> shift for every float that is not a sign-set NaN (those give maxVal).
+ * info = {ok, mantissa bits of the key, shift, kmin, nbuckets}; ok = 0 when the table does not qualify (NaNs,
+ * decreasing or duplicate entries, too many records) and the kernels run the literal bisection instead.
+ * rec_out (nullable, rec_cap entries) receives the records. */
+int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
+
+/* Host-only (no GPU, no context): the two per-stream tables of the YCbCr kernels, built with the host libm as the reference
+ * would evaluate them per pixel.  (1) The threshold records -- same format and lookup as lumahip_thresh_index_host, for
+ * arguments t >= +0 or NaN -- of the composite function  t -> quantize(PQdec(t / 255), 0)  with t = 219 y + 16, y the pixel's luma
+ * (src/luma_quantizer.cpp:337, 496-500, 222-235), from which the encode kernels take a pixel's luminance code.
+ * (2) out[i] = (255 PQenc(lut[i]) - 16) / 219 (src/luma_quantizer.cpp:447-448, 491-494), which the decode kernels read
+ * instead of evaluating PQenc per pixel. */
+int lumahip_ycbcr_luma_index_host(const float *lut, size_t n, float maxLum, int info[5], uint32_t *rec_out, size_t rec_cap);
+int lumahip_ycbcr_ytab_host(const float *lut, size_t n, float maxLum, float *out);
+
+/* Synthetic benchmark input, generated on the device by the integer-only recipe of SURVEY.md 8(d)
+ * (identical to the oracle's lo_synth_frame): frame index first_frame + f at dst_dev + f*frame_stride. */
+int lumahip_synth_frames_device(lumahip_ctx *ctx, float *dst_dev, size_t frame_stride, unsigned nframes,
+                                unsigned w, unsigned h, uint64_t seed, uint64_t first_frame);
+
+/* Timing helper for benchmarks: runs `iters` encode (dir=0) or decode (dir=1) launches of the same
+ * arguments back to back on the context's stream between two hipEvents and returns the average
+ * kernel-launch duration in milliseconds (events are recorded on the stream the kernels run on). */
+int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb_dev, size_t frame_stride,
+                          unsigned nframes, unsigned w, unsigned h, float sc, int profile,
+                          unsigned char *const planes_dev[3], const int stride[3],
+                          const size_t plane_frame_stride[3], float *avg_ms);
+
+/* Test probe: the luminance search exactly as the encode kernels instantiate it (four values per thread, the
+ * context's search mode; nonneg != 0 selects the Lu'v' kernels' variant, which relies on every value being >= 0 or NaN)
+ * over the n consecutive fp32 bit patterns first_bits, first_bits+1, ...: out_dev[i] = code.  n % 4 == 0.
+ * Counterpart of LumaQuantizer::quantize(val, 0) (src/luma_quantizer.cpp:222-235). */
+int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg);
+
+/* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
+ * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the
+ * device function with the host libm exhaustively. */
+int lumahip_powf_probe_device(lumahip_ctx *ctx, float *out_dev, uint32_t first_bits, size_t n, float y, int regular);
+
+/* Test probe (YCbCr quantizers): out[i] = the luminance code of a pixel whose t = 219 y + 16 (y = its luma,
+ * src/luma_quantizer.cpp:335-337) is the float with bit pattern first_bits + i.  direct = 0: through the composite threshold
+ * records exactly as the encode kernels read them; direct = 1: the reference's arithmetic, PQdec(t / 255) then LumaQuantizer::quantize(., 0)
+ * (src/luma_quantizer.cpp:337, 496-500, 222-235), evaluated on the device with the complete powf and IEEE division.
+ * n % 4 == 0.  LUMAHIP_ERR_UNSUPPORTED when the table has no composite records. */
+int lumahip_ycbcr_luma_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int direct);
+
+/* Benchmark probe: the loads and stores of the 4:2:0 16-bit encode kernel with no arithmetic in between (same
+ * tile order, same access widths, non-temporal), `iters` launches, average milliseconds.  OVERWRITES the planes
+ * with garbage.  What the memory system alone needs for the encode traffic mix on this device. */
+int lumahip_probe_encode_traffic_device(lumahip_ctx *ctx, const float *rgb_dev, size_t frame_stride, unsigned nframes,
+                                        unsigned w, unsigned h, unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], int iters, float *avg_ms);
+
+/* The decode counterpart: the loads and stores of the 4:2:0 16-bit decode kernel (3 B read + 12 B written per pixel) with no
+ * arithmetic.  OVERWRITES the frames with garbage.  Float frames as in lumahip_decode_frames_device_planar. */
+int lumahip_probe_decode_traffic_device(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                        const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
+                                        float *const rgb_planes_dev[3], size_t frame_stride, int iters, float *avg_ms);
+
+#endif /* LUMAHIP_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

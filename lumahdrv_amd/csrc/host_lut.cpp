@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#define LUMAHIP_EXPERIMENTAL   /* the library defines what the experimental section of the header declares */
 #include "../../include/lumahip.h"
 #include "host_lut.hpp"
 #include "lut_index.hpp"

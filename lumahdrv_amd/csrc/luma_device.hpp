@@ -176,7 +176,7 @@ LH_DEV float pq_decode(float val, const K &k)
 // The same two functions on the branch-free powf.  A SlowAcc collects, over as many pixels as the caller likes (the
 // kernels: one thread's whole unit), whether any argument left the domain in which the straight-line arithmetic
 // (powf_regular, div_nr) is licensed; the caller then redoes those pixels with the complete functions and IEEE division
-// throughout.  Two collectors, because a compare costs twice an integer max (tools/valu_bench.hip) and keeps a lane
+// throughout.  Two collectors, because a compare costs twice an integer max (tools/bench/valu_bench.hip) and keeps a lane
 // mask alive in scalar registers: `umax` = running unsigned max of (bits(x) - 0x00800000) over arguments that must be
 // positive normal floats (one compare against 0x7f000000 at the end), `flag` for the tests that need their own compare.
 // Lmax in [1e-6, 1e9] is checked by the caller.

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#define LUMAHIP_EXPERIMENTAL   /* the library defines what the experimental section of the header declares */
 #include "../../include/lumahip.h"
 #include "luma_kernels.hpp"
 #include "host_lut.hpp"

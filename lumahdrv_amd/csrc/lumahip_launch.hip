@@ -56,9 +56,9 @@ int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves)
 // Persistent workgroups: how many of them.  dir 0 = encode, 1 = decode.  The default is 2048 threads' worth per CU (8
 // workgroups of 256), i.e. MORE than are resident at once for most kernels: the surplus is dispatched as resident ones
 // retire, which evens out the tail of short launches.  The rules below were found on 20 x 3840x2160 launches by running both
-// settings in one process (tools/ab_inproc.py, profiles/r02_grid_sweep.txt) and then re-derived over {720p, 1080p, 4K, 8K} x
+// settings in one process (tools/bench/ab_inproc.py, profiles/r02_grid_sweep.txt) and then re-derived over {720p, 1080p, 4K, 8K} x
 // {1, 2, 4, 8, 20, 50 frames} x {Lu'v', YCbCr} x {encode, decode} with every setting interleaved in one process
-// (tools/launch_rules_sweep.py, profiles/r03_launch_rules.txt: before / after tables).  lumahip_tune "grid_enc" / "grid_dec"
+// (tools/bench/launch_rules_sweep.py, profiles/r03_launch_rules.txt: before / after tables).  lumahip_tune "grid_enc" / "grid_dec"
 // (absolute) and "blocks_per_cu" (per CU, both directions) are measurement overrides.
 int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers, int ycbcr)
 {
@@ -100,7 +100,7 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int fe
     // of LDS) is resident per CU; every further one stages the 124 KiB table anew.  Short launches want exactly the resident
     // set (720p x4: 16.2 us against 19.6 with 2 or more per CU; 1080p x1: 15.1 / 17.4; 4K x1: 28.6 / 30.4), long ones many small
     // static shares as the other YCbCr kernels do (4K x20: 422 us with 12 per CU against 466 with 2; 8K x20: 1659 / 1790);
-    // profiles/r04_half_table_grid.txt, tools/half_grid_sweep.py.
+    // profiles/r04_half_table_grid.txt, tools/bench/half_grid_sweep.py.
     if (ycbcr == 2 && rule && threads == 1024)
         per_cu = total_tiles < 3000 ? 1 : total_tiles < 12000 ? 3 : 12;
     long g = (long)c->num_cu * per_cu;

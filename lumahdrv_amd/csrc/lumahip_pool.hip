@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#define LUMAHIP_EXPERIMENTAL   /* the pool finds the region groups with the traffic probe */
 #include "../../include/lumahip.h"
 
 namespace {

@@ -253,7 +253,7 @@ LH_HD uint32_t pw_range_low(const PowfTablesWide &) { return 0x3f330000u - (64u 
 // when ZERO) with |y*log2(x)| < 126; y is one of the four positive PQ exponents.  For those arguments it performs
 // exactly the arithmetic of powf_glibc above (same operations, same order) without any of its branches; for
 // everything else it sets `slow` and returns garbage -- the caller then redoes the pixel with powf_glibc.
-// What is tested is a template choice, because each test costs a half-rate compare (tools/valu_bench.hip) and the
+// What is tested is a template choice, because each test costs a half-rate compare (tools/bench/valu_bench.hip) and the
 // call sites can often prove a test away (luma_device.hpp states the argument range at each one):
 //   ZERO    x may be +0: pow(+0, y > 0) = +0 is folded in as a select (black pixels are common on the decode side);
 //   CHECK_X x may be anything: raise `slow` unless it is a positive normal finite float (or +0 when ZERO);

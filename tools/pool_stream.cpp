@@ -18,6 +18,7 @@
 #include <cstring>
 #include <vector>
 
+#define LUMAHIP_EXPERIMENTAL   /* the traffic probe and the synthetic frames are measurement hooks */
 #include "lumahip.h"
 
 namespace {

@@ -13,7 +13,7 @@ lh::k_synth writes a known byte count with 4-B stores (WRITE_SIZE ratio printed)
 reads are 8-B / 4-B per lane (factor reported as measured/algorithmic, not assumed).
 
 VALU issue cycles = sum over instruction classes of PMC count x issue cost per wave64 instruction measured with
-tools/valu_bench.hip on MI355X (profiles/r02_valu_issue_rates.txt): fp32 add/mul/fma and int32 2 cycles, fp64 4,
+tools/bench/valu_bench.hip on MI355X (profiles/r02_valu_issue_rates.txt): fp32 add/mul/fma and int32 2 cycles, fp64 4,
 conversions 4, fp32 transcendentals 8, everything the class counters do not name (compares, selects, min/max/med3,
 moves, permutes, 64-bit integer) 4 -- an upper estimate for that remainder (moves issue in 2).
 """
@@ -245,7 +245,7 @@ def main():
     if "encode" in mixes:
         update_json(os.path.join(dst, "valu_mix_latest.json"), wl,
                     dict(mixes["encode"], tag=tag, workload=wl, kernel_source_sha=sha, commit=commit, decode=mixes.get("decode"),
-                         note="PMC class counters x issue costs of tools/valu_bench.hip (tools/summarize_profile.py)"))
+                         note="PMC class counters x issue costs of tools/bench/valu_bench.hip (tools/summarize_profile.py)"))
     print("\n".join(lines[-24:]))
 
 
