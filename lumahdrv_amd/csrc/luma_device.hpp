@@ -120,7 +120,7 @@ LH_DEV float div_255_pos(float a)
 //   xform_fwd: in = r*sc, g*sc, b*sc (the caller applies the reference's `*sc` -- and skips it when
 //              sc == 1.0f, x*1.0f being exact); out = the three channel values the reference stores back.
 //   xform_inv: out = the reference's values BEFORE its final `/sc` (the caller divides -- and skips the
-//              division when sc == 1.0f, x/1.0f being exact).
+//              division when sc == 1.0f, x/1.0f being exact).  Exception: ycbcr_inv_n divides itself.
 // ---------------------------------------------------------------------------------------------------
 
 // Tab: which powf tables the YCbCr path reads -- PowfTablesWide (33 KiB, one LDS read per log2) everywhere except the
@@ -134,6 +134,11 @@ struct XformConstT {
     // refined reciprocals (rcp_nr) of the YCbCr path's constant divisors, computed once per thread instead of once
     // per division: div_nr_r(a, b, rcp_nr(b)) is div_nr(a, b) by definition
     float rLmax, r18814, r14746, r224, r0678;
+    // YCbCr decode: the final `/ sc` (src/luma_quantizer.cpp:466-468).  sc_mode 0: sc == 1.0f, nothing to do; 1: sc is a normal
+    // float in [2^-16, 2^16] and the quotients take the short division on rsc = rcp_nr(sc) (ycbcr_inv_n<., ., SCDIV> states the
+    // licence); 2: anything else -- the complete functions with IEEE division
+    float rsc;
+    int sc_mode;
 };
 using XformConst = XformConstT<PowfTablesWide>;
 
@@ -144,8 +149,15 @@ LH_DEV XformConstT<Tab> make_xform_const(float sc, float Lmax, const Tab *pw)
     k.sc = sc;
     k.Lmax = Lmax;
     k.pw = pw;
-    k.rLmax = k.r18814 = k.r14746 = k.r224 = k.r0678 = 0.0f;
+    k.rLmax = k.r18814 = k.r14746 = k.r224 = k.r0678 = k.rsc = 0.0f;
+    k.sc_mode = (sc == 1.0f) ? 0 : 2;
     if constexpr (CS == CS_YCBCR) {
+#ifndef LH_NO_FAST_DIV
+        if (sc != 1.0f && sc >= 0x1p-16f && sc <= 0x1p16f) {
+            k.sc_mode = 1;
+            k.rsc = rcp_nr(sc);
+        }
+#endif
         k.rLmax = rcp_nr(Lmax);
         k.r18814 = rcp_nr(1.8814f);
         k.r14746 = rcp_nr(1.4746f);
@@ -219,14 +231,18 @@ LH_DEV float pq_encode_r(float val, const K &k, SlowAcc &acc)
 // a normal float -- it is a sum / difference of floats whose granularity is far above 2^-126 (ycbcr_inv), never a
 // denormal; Vp <= c1 gives a quotient of exactly 0 (ZERO) and Vp just above c1 one small enough for |log2|/n >= 126
 // (CHECK_E); the quotient itself is 0 or in [3e-9, 6.4], a normal float.
-template <bool BOUNDED, typename K>
+// POSVAL (decode side, round 4): the caller has raised val to at least 2^-21 (see ycbcr_inv), so the first power needs no
+// zero select either; the quotient can still be exactly 0 (Vp <= c1) and tiny, hence ZERO and CHECK_E on the second.
+// ELIM: the bound on |log2| of the second power at which the unit goes to the complete functions: 126 where only powf's own
+// under / overflow handling must be avoided, 56 where the caller wants the result in [2^-56, 2^56] (ycbcr_inv_n<., ., 1>).
+template <bool BOUNDED, bool POSVAL = false, int ELIM = 1, typename K>
 LH_DEV float pq_decode_r(float val, const K &k, SlowAcc &acc)
 {
     const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
-    const float Vp = powf_regular<!BOUNDED, false, false>(val, 1.0f / m, *k.pw, acc.flag);
+    const float Vp = powf_regular<!BOUNDED && !POSVAL, false, false>(val, 1.0f / m, *k.pw, acc.flag);
     // std::max(0.0f, Vp - c1): with BOUNDED the difference is positive and the max is the identity
     const float num = BOUNDED ? Vp - c1 : std_max(0.0f, Vp - c1);
-    return k.Lmax * powf_regular<!BOUNDED, false, !BOUNDED>(div_nr(num, c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
+    return k.Lmax * powf_regular<!BOUNDED, false, BOUNDED ? 0 : ELIM>(div_nr(num, c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
 }
 
 template <int CS>
@@ -444,7 +460,7 @@ LH_DEVS void xform_inv<CS_PACK>(float c0, float c1, float c2, const XformConst &
 // YT: c0 is already y = (255 PQenc(table value) - 16) / 219, read from the per-stream table the host built with its libm
 // (host_lut.cpp ycbcr_ytab_host; QuantDev::ytab): the first of the four PQ evaluations of a pixel depends on the luminance
 // CODE alone, so it is done once per table entry and stream instead of once per pixel.
-template <bool REGULAR, bool YT = false, typename K>
+template <bool REGULAR, bool YT = false, int ELIM = 1, bool CT = false, typename K>
 LH_DEV void ycbcr_inv(float c0, float c1, float c2, const K &k, float &r, float &g, float &b, SlowAcc &slow)
 {
     float y, blue, red, green;
@@ -455,8 +471,13 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const K &k, float &r, float 
             y = c0;
         else
             y = div_219_fin(255.0f * pq_encode_r<true>(c0, k, slow) - 16.0f);
-        blue = y + div_nr_r(1.8814f * (255.0f * c1 - 128.0f), 224.0f, k.r224);
-        red = y + div_nr_r(1.4746f * (255.0f * c2 - 128.0f), 224.0f, k.r224);
+        if constexpr (CT) {   // c1, c2 are already the chroma TERMS, read from the per-code tables (ycbcr_chroma_term)
+            blue = y + c1;
+            red = y + c2;
+        } else {
+            blue = y + div_nr_r(1.8814f * (255.0f * c1 - 128.0f), 224.0f, k.r224);
+            red = y + div_nr_r(1.4746f * (255.0f * c2 - 128.0f), 224.0f, k.r224);
+        }
         green = div_nr_r((y - 0.2627f * red) - 0.0593f * blue, 0.6780f, k.r0678);
     } else {
         if constexpr (YT)
@@ -467,47 +488,118 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const K &k, float &r, float 
         red = y + div_ieee(1.4746f * (255.0f * c2 - 128.0f), 224.0f);
         green = div_ieee((y - 0.2627f * red) - 0.0593f * blue, 0.6780f);
     }
-    // (the compiler turns these compare + select pairs into v_min_f32 / v_max_f32 itself: a NaN becomes 1, -0 becomes +0)
-    red = std_max(0.0f, std_min(1.0f, red));
-    green = std_max(0.0f, std_min(1.0f, green));
-    blue = std_max(0.0f, std_min(1.0f, blue));
     if constexpr (REGULAR) {
-        // The powers below take arguments that are +0 or at least 2^-64 (the wide log2 table of pow_glibc.hpp).  red and
-        // blue: y is 0 or |y| >= 2^-20/219 (255*P - 16 is a multiple of 2^-20 where it can cancel), the chroma term is 0 or
-        // >= 2^-17*1.47/224 likewise, so their float sum is 0 or a multiple of 2^-51.  green is a difference of
-        // differences and has no such bound that is short to prove: it joins the running minimum (one subtract and one
-        // unsigned min per pixel), and a pixel below the bound sends the unit to the complete functions.
-        slow.umin = min(slow.umin, __float_as_uint(green) - 1u);
-        r = pq_decode_r<false>(red, k, slow);
-        g = pq_decode_r<false>(green, k, slow);
-        b = pq_decode_r<false>(blue, k, slow);
+        // The reference clamps to [0, 1] (src/luma_quantizer.cpp:460-462) and evaluates PQdec.  Every value below
+        // c1^m = 0.8359^78.8438 = 7.3e-7 decodes to exactly 0: Vp = val^(1/m) <= c1, so std::max(0, Vp - c1) = 0, the quotient is 0
+        // and L * 0^(1/n) = 0.  Clamping to [2^-21, 1] instead (2^-21 = 4.8e-7: Vp = 0.8314 < c1) therefore changes no result
+        // and hands the first power a positive normal argument in every case: no zero select, no lower-bound test for green
+        // (a difference of differences with no short proof of one), same two instructions for the clamp.  (The compiler turns
+        // the compare + select pairs into v_min_f32 / v_max_f32: a NaN becomes 1, as in the reference's std::min / std::max.)
+        red = std_max(0x1p-21f, std_min(1.0f, red));
+        green = std_max(0x1p-21f, std_min(1.0f, green));
+        blue = std_max(0x1p-21f, std_min(1.0f, blue));
+        r = pq_decode_r<false, true, ELIM>(red, k, slow);
+        g = pq_decode_r<false, true, ELIM>(green, k, slow);
+        b = pq_decode_r<false, true, ELIM>(blue, k, slow);
     } else {
+        red = std_max(0.0f, std_min(1.0f, red));
+        green = std_max(0.0f, std_min(1.0f, green));
+        blue = std_max(0.0f, std_min(1.0f, blue));
         r = pq_decode(red, k);
         g = pq_decode(green, k);
         b = pq_decode(blue, k);
     }
 }
 
-template <int N, bool YT = false, typename K>
-LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
-                        float (&g)[N], float (&b)[N])
+// colour-channel dequantizer: std::max(val/maxC, 1e-10f), src/luma_quantizer.cpp:261 (dequantize_color further down is the same)
+LH_DEV float dequantize_color_ieee(int code, float maxC) { return std_max(div_ieee((float)code, maxC), 1e-10f); }
+
+// The chroma term of a colour code: what src/luma_quantizer.cpp:261 (dequantize) and :450-451 make of it before y is added,
+//   Cb: 1.8814 (255 c - 128) / 224,  Cr: 1.4746 (255 c - 128) / 224,  c = std::max(code / maxC, 1e-10f)
+// with IEEE division.  The YCbCr decode kernels keep it per code in LDS (stage_tables, STAGE_CT): two dequantisations, four
+// products / differences and two divisions per 2x2 quad become two LDS reads.
+LH_DEV float ycbcr_chroma_term(int code, float maxC, float coef)
 {
+    const float c = std_max(div_ieee((float)code, maxC), 1e-10f);
+    return div_ieee(coef * (255.0f * c - 128.0f), 224.0f);
+}
+
+// The reference's final `/ sc` (src/luma_quantizer.cpp:466-468) is part of this function since round 4 (xform_inv's other
+// colour spaces leave it to the caller).  SCDIV is how the STRAIGHT-LINE code treats it -- a template choice, because a run-time
+// choice between "nothing", five fused multiply-adds and an IEEE division is turned into all three plus selects by the compiler:
+//   -1  never divide: the values are the reference's before that division (xform_inv's contract; k_transform divides itself);
+//    0  no division in the straight-line code: right for sc == 1 (k.sc_mode 0); with k.sc_mode 2 (sc outside [2^-16, 2^16],
+//       or the LH_NO_FAST_DIV build) the unit is sent to the complete functions below, which divide with IEEE division;
+//    1  k.sc_mode == 1: sc is a normal float in [2^-16, 2^16].  A decoded value is 0 or L * P, and the second power of PQdec
+//       sends the unit to the complete functions unless P lies in [2^-56, 2^56] (ELIM = 56 instead of powf's own 126: the
+//       same compare, another constant; what it newly turns away are values below 1e-17 of the peak), L in [2^-20, 2^30]: operands
+//       and quotients are normal and their exponents less than 96 apart, so div_nr_r on the refined reciprocal of sc IS the
+//       IEEE quotient (see div_nr) -- five instructions instead of eleven; 0 / sc = +0 either way.
+// CT: c1 / c2 are the chroma TERMS of the two colour codes (ycbcr_chroma_term, read from LDS by the caller) and code1 / code2
+//     the codes themselves, which only the complete functions look at; bad_code = some code exceeds maxC (the tables end there).
+// element i of a small register array, i known only at run time (cold code): a chain of selects, so that the array stays in registers
+template <int M>
+LH_DEV int pick(const int (&a)[M], int i)
+{
+    int v = a[0];
+#pragma unroll
+    for (int j = 1; j < M; j++)
+        v = (i == j) ? a[j] : v;
+    return v;
+}
+
+// NC / SUB: code1 / code2 hold one entry per 2x2 quad of the unit (SUB, N = 2 * VW pixels in two rows of VW) or one per pixel
+template <int N, bool YT = false, int SCDIV = 0, bool CT = false, int NC = 1, bool SUB = false, typename K>
+LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
+                        float (&g)[N], float (&b)[N], const int (&code1)[NC], const int (&code2)[NC], float maxC, bool bad_code)
+{
+    constexpr int ELIM = SCDIV == 1 ? 56 : 1;
     SlowAcc slow;
-    slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f);
+    slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f) || (SCDIV == 0 && k.sc_mode == 2) || (CT && bad_code);
 #pragma unroll
     for (int i = 0; i < N; i++) {
         // out-of-range colour codes (c1, c2 > 1) or a non-finite table value leave the licensed ranges: slow path
         // (YT: the y table exists only for tables whose entries are all finite and non-negative, lumahip_core.hip)
-        if constexpr (YT)
+        if constexpr (CT)
+            ;   // (bad_code says it)
+        else if constexpr (YT)
             slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f);
         else
             slow.flag = slow.flag || !(c1[i] <= 1.0f && c2[i] <= 1.0f && c0[i] <= 3.0e38f);
-        ycbcr_inv<true, YT>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+        ycbcr_inv<true, YT, ELIM, CT>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+    }
+    if constexpr (SCDIV == 1) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            r[i] = div_nr_r(r[i], k.sc, k.rsc);
+            g[i] = div_nr_r(g[i], k.sc, k.rsc);
+            b[i] = div_nr_r(b[i], k.sc, k.rsc);
+        }
     }
     if (__builtin_expect(slow_any(slow, k), 0)) {
-        for (int i = 0; i < N; i++)  // not unrolled: cold code
-            ycbcr_inv<false, YT>(c0[i], c1[i], c2[i], k, r[i], g[i], b[i], slow);
+        for (int i = 0; i < N; i++) {  // not unrolled: cold code
+            float d1 = c1[i], d2 = c2[i];
+            if constexpr (CT) {
+                const int j = SUB ? (i % (N / 2)) / 2 : i;
+                d1 = dequantize_color_ieee(pick(code1, j), maxC);
+                d2 = dequantize_color_ieee(pick(code2, j), maxC);
+            }
+            ycbcr_inv<false, YT>(c0[i], d1, d2, k, r[i], g[i], b[i], slow);
+            if (SCDIV >= 0) {
+                r[i] = div_ieee(r[i], k.sc);   // (x / 1.0f == x)
+                g[i] = div_ieee(g[i], k.sc);
+                b[i] = div_ieee(b[i], k.sc);
+            }
+        }
     }
+}
+
+template <int N, bool YT = false, int SCDIV = 0, typename K>
+LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
+                        float (&g)[N], float (&b)[N])
+{
+    const int none[1] = {0};
+    ycbcr_inv_n<N, YT, SCDIV, false, 1, false>(c0, c1, c2, k, r, g, b, none, none, 0.0f, false);
 }
 
 template <>
@@ -515,7 +607,7 @@ LH_DEVS void xform_inv<CS_YCBCR>(float c0, float c1, float c2, const XformConst 
 {
     const float i0[1] = {c0}, i1[1] = {c1}, i2[1] = {c2};
     float ro[1], go[1], bo[1];
-    ycbcr_inv_n<1>(i0, i1, i2, k, ro, go, bo);
+    ycbcr_inv_n<1, false, -1>(i0, i1, i2, k, ro, go, bo);
     r = ro[0];
     g = go[0];
     b = bo[0];

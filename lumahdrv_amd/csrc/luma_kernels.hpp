@@ -80,10 +80,11 @@ struct DecArgs {
 
 // LDS layout: [powf tables (YCbCr only; FIRST, so that their addresses are immediates in the powf chains)]
 // [lut: lut_len+pad floats, rounded to 16 B | records: nbuckets u32, rounded to 16 B]
+// [YCbCr decode with per-stream tables: y table (as long as the lut), then the Cb and Cr chroma-term tables, maxC+1 floats each]
 // [u'v' table: maxC+1 floats (Lu'v' decode only), see luv_chroma_uv | half-input table (YCbCr encode, LM == 6)].
 // Which parts a kernel stages is a compile-time set (encode: records; decode: the table).
 // STAGE_POWFN: the 768-byte powf tables instead of the wide ones (the half-input kernels: their LDS belongs to the half table).
-enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16, STAGE_YT = 32, STAGE_POWFN = 64, STAGE_HALF = 128 };
+enum : int { STAGE_LUT = 1, STAGE_REC = 4, STAGE_POWF = 8, STAGE_UV = 16, STAGE_YT = 32, STAGE_POWFN = 64, STAGE_HALF = 128, STAGE_CT = 256 };
 
 // fill the LDS copy of the powf tables (pow_glibc.hpp); the caller synchronises
 LH_DEV void stage_powf_tables(PowfTables *t)
@@ -159,6 +160,17 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, const float *ha
         float4 *s = reinterpret_cast<float4 *>(smem + off + lds_lut_bytes(q));
         for (int i = tid; i < n4; i += nt)
             s[i] = g[i];
+    }
+    if constexpr (WHAT & STAGE_CT) {
+        // YCbCr decode: the chroma terms of every colour code (luma_device.hpp ycbcr_chroma_term), Cb table then Cr table,
+        // behind the luminance table and the y table
+        static_assert((WHAT & STAGE_YT), "the chroma-term tables sit behind the y table");
+        float *ct = reinterpret_cast<float *>(smem + off + 2 * lds_lut_bytes(q));
+        const int n = (int)q.maxC + 1;
+        for (int i = tid; i < n; i += nt) {
+            ct[i] = ycbcr_chroma_term(i, q.maxC, 1.8814f);
+            ct[n + i] = ycbcr_chroma_term(i, q.maxC, 1.4746f);
+        }
     }
     if constexpr (WHAT & STAGE_UV) {
         static_assert(WHAT & STAGE_LUT, "the u'v' table sits behind the luminance table");
@@ -663,8 +675,9 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
-template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, typename LutPtr>
-LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const XformConst &k, LutPtr lut, const float *s_uv)
+// SCFAST (YCbCr): the straight-line code divides by sc with the short division (XformConst::sc_mode == 1, ycbcr_inv_n)
+template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, bool SCFAST = false, typename LutPtr, typename K>
+LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k, LutPtr lut, const float *s_uv)
 {
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
     const float maxC = a.q.maxC;
@@ -675,7 +688,9 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
 #pragma unroll
         for (int i = 0; i < VW; i++)
             c0[r * VW + i] = dequantize_lut(u.y[r][i], YT ? LutPtr(s_uv) : lut, maxVal);   // YT: the y table (behind the table in LDS)
-    if constexpr (SUB) {
+    if constexpr (CS == CS_YCBCR && YT) {
+        // (the chroma samples are read as terms from the per-code tables below)
+    } else if constexpr (SUB) {
         constexpr int NQ = VW / 2;
 #pragma unroll
         for (int qd = 0; qd < NQ; qd++) {
@@ -718,7 +733,29 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
                 luv_apply(c0[r * VW + i], ch[SUB ? i / 2 : r * VW + i], out[0][r][i], out[1][r][i], out[2][r][i]);
     } else if constexpr (CS == CS_YCBCR) {
         float r8[2 * VW], g8[2 * VW], b8[2 * VW];
-        ycbcr_inv_n<2 * VW, YT>(c0, c1, c2, k, r8, g8, b8);
+        if constexpr (YT) {
+            // the chroma terms from the per-code tables behind the y table (stage_tables, STAGE_CT); the codes themselves go
+            // along for the complete functions, which a code beyond maxC (garbage from a lossy upstream decoder) calls for
+            constexpr int NC = SUB ? VW / 2 : 2 * VW;
+            const int maxCi = (int)maxC;
+            const float *s_cb = s_uv + (a.q.lut_len + a.q.pad), *s_cr = s_cb + (maxCi + 1);
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                bad = bad || u.c1[j] > maxCi || u.c2[j] > maxCi;
+                const float t1 = s_cb[min(u.c1[j], maxCi)], t2 = s_cr[min(u.c2[j], maxCi)];
+                if constexpr (SUB) {
+                    c1[2 * j] = c1[2 * j + 1] = c1[VW + 2 * j] = c1[VW + 2 * j + 1] = t1;
+                    c2[2 * j] = c2[2 * j + 1] = c2[VW + 2 * j] = c2[VW + 2 * j + 1] = t2;
+                } else {
+                    c1[j] = t1;
+                    c2[j] = t2;
+                }
+            }
+            ycbcr_inv_n<2 * VW, true, SCFAST ? 1 : 0, true, NC, SUB>(c0, c1, c2, k, r8, g8, b8, u.c1, u.c2, maxC, bad);
+        } else {
+            ycbcr_inv_n<2 * VW, YT, SCFAST ? 1 : 0>(c0, c1, c2, k, r8, g8, b8);
+        }
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -734,7 +771,7 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const Xform
             for (int i = 0; i < VW; i++)
                 xform_inv<CS>(c0[r * VW + i], c1[r * VW + i], c2[r * VW + i], k, out[0][r][i], out[1][r][i], out[2][r][i]);
     }
-    if (k.sc != 1.0f) {  // wave-uniform; x/1.0f == x, so the division is skipped for the default preScaling
+    if (CS != CS_YCBCR && k.sc != 1.0f) {  // wave-uniform; x/1.0f == x, so the division is skipped for the default preScaling (YCbCr: ycbcr_inv_n has divided)
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -799,11 +836,14 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     static_assert(!YT || (CS == CS_YCBCR && !GL), "the y table belongs to the YCbCr kernels with the table in LDS");
     // GL: transfer-function table or chroma depth beyond 12 bits -- tables stay in global memory / are not built
     constexpr bool UVTAB = (CS == CS_LUV && !GL);
-    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0) | (YT ? STAGE_YT : 0);
+    // (The 16-entry powf tables instead -- no LDS bank conflicts, ten more issue cycles per powf -- were tried for this kernel
+    // once the round-4 changes had cut its VALU work by 13 %: 3.3 % slower, 1.296 against 1.253 ms per 20 x 4K, same box.)
+    using DecTab = PowfTablesWide;
+    constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0) | (YT ? STAGE_YT | STAGE_CT : 0);
     stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
     const float *s_uv = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_lut_bytes(a.q));
-    const XformConst k = make_xform_const<CS>(a.sc, a.q.Lmax, reinterpret_cast<const PowfTablesWide *>(smem));
+    const XformConstT<DecTab> k = make_xform_const<CS, DecTab>(a.sc, a.q.Lmax, reinterpret_cast<const DecTab *>(smem));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -813,10 +853,24 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
         if (cur.valid) {
-            if constexpr (GL)
+            if constexpr (CS == CS_YCBCR) {
+                // two copies of the unit's code, chosen by a kernel argument: see ycbcr_inv_n on why not a run-time choice inside
+                if (k.sc_mode == 1) {
+                    if constexpr (GL)
+                        dec_process<CS, SUB, VW, DISP, false, false, true>(cur, a, k, a.q.lut, s_uv);
+                    else
+                        dec_process<CS, SUB, VW, DISP, UVTAB, YT, true>(cur, a, k, s_lut, s_uv);
+                } else {
+                    if constexpr (GL)
+                        dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
+                    else
+                        dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv);
+                }
+            } else if constexpr (GL) {
                 dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
-            else
+            } else {
                 dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv);
+            }
         }
         // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
         // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)

@@ -397,7 +397,7 @@ static int upload_table(lumahip_ctx *c)
         bool ok = true;
         for (size_t i = 0; i < n && ok; i++)
             ok = c->h_lut[i] >= 0.0f && c->h_lut[i] <= 3.0e38f;
-        const size_t both = 2 * (((n + 4) * sizeof(float) + 15) & ~(size_t)15) + 64 + powf_b;
+        const size_t both = 2 * (((n + 4) * sizeof(float) + 15) & ~(size_t)15) + ((size_t)8 << c->bitdepthC) + 64 + powf_b;   // + the two chroma-term tables
         if (ok && both <= LUMAHIP_LDS_PER_WORKGROUP) {
             std::vector<float> yt(lut_floats, 0.0f);
             ycbcr_ytab_host(c->h_lut.data(), n, c->q.Lmax, yt.data());

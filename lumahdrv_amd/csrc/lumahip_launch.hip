@@ -25,7 +25,7 @@ size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode,
         if (cs_eff == CS_LUV)
             b += (((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15;  // u'v' table of the Lu'v' decode kernels
         if (cs_eff == CS_YCBCR && q.ytab)
-            b += lut_b;                                          // y table of the YCbCr decode kernels
+            b += lut_b + 2 * ((((size_t)q.maxC + 1) * 4 + 15) & ~(size_t)15);   // y table + the two chroma-term tables of the YCbCr decode kernels
     }
     if (encode_side && ycode && half)   // the half-input kernels: the table, and the small powf tables for their general path
         return b + (size_t)lds_half_bytes() + sizeof(PowfTables);

@@ -257,9 +257,10 @@ LH_HD uint32_t pw_range_low(const PowfTablesWide &) { return 0x3f330000u - (64u 
 // call sites can often prove a test away (luma_device.hpp states the argument range at each one):
 //   ZERO    x may be +0: pow(+0, y > 0) = +0 is folded in as a select (black pixels are common on the decode side);
 //   CHECK_X x may be anything: raise `slow` unless it is a positive normal finite float (or +0 when ZERO);
-//   CHECK_E |y*log2(x)| may reach 126 (over/underflow handling of e_powf.c): raise `slow` then.
+//   CHECK_E |y*log2(x)| may reach 126 (over/underflow handling of e_powf.c): raise `slow` then.  (1 / true: at 126; any other
+//           non-zero value: already at that bound -- a caller that wants the result's exponent inside a narrower range.)
 // powf_regular<true, true, true> accepts every argument and is what tests/test_gpu_exhaustive.py sweeps.
-template <bool ZERO, bool CHECK_X, bool CHECK_E, typename Tab>
+template <bool ZERO, bool CHECK_X, int CHECK_E, typename Tab>
 LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
 {
     const uint32_t ix = pw_asuint(x);
@@ -285,8 +286,11 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
     q = __builtin_fma(p, r2, q);
     yy = __builtin_fma(yy, r4, q);
     const double ylogx = (double)y * yy;
-    if (CHECK_E)
-        slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(126.0) >> 47)));
+    if (CHECK_E) {
+        // the limit's top five mantissa bits are all the compare sees: 126 and 56 are exact in them
+        const double lim = CHECK_E == 1 ? 126.0 : (double)CHECK_E;
+        slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(lim) >> 47)));
+    }
     const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
     const double SHIFT = 0x1.8p+52 / 32;
     double kd = ylogx + SHIFT;
