@@ -190,7 +190,9 @@ void LumaDecoderBase::seekToTime(float tm, bool absolute)
         m_time = 0.0f;
     LumaPlaneSource *src = getReader();
     const float fd = src->getFrameDuration();
-    const float fps = fd > 0.0f ? 1.0f / fd : 25.0f;
+    float fps = fd > 0.0f ? 1.0f / fd : 25.0f;
+    if (src == &m_rawReader && m_rawReader.fps() > 0.0f)
+        fps = m_rawReader.fps();   // (the stream's own figure, not the reciprocal of its reciprocal)
     src->seekToFrame((unsigned int)(m_time * fps));
     m_firstFrame = false;
 }

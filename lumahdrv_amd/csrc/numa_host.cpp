@@ -127,17 +127,35 @@ bool numa_pin_thread(pthread_t t, const std::vector<int> &cpus)
     return pthread_setaffinity_np(t, sizeof set, &set) == 0;
 }
 
+// set_mempolicy(2) / get_mempolicy(2) without libnuma: MPOL_DEFAULT = 0, MPOL_PREFERRED = 1; the node mask is a bit field of
+// maxnode bits.  The policy the thread had (a caller may run under `numactl --interleave`) is kept and put back.
+namespace {
+thread_local int t_saved_mode = -1;
+thread_local unsigned long t_saved_mask[16];
+}  // namespace
+
 bool numa_prefer_node(int node)
 {
-    // set_mempolicy(2) without libnuma: MPOL_DEFAULT = 0, MPOL_PREFERRED = 1; the node mask is a bit field of maxnode bits
-    if (node < 0)
-        return syscall(SYS_set_mempolicy, 0, nullptr, 0) == 0;
+    if (node < 0) {
+        if (t_saved_mode < 0)
+            return true;
+        const int mode = t_saved_mode;
+        t_saved_mode = -1;
+        return syscall(SYS_set_mempolicy, mode, mode == 0 ? nullptr : t_saved_mask, mode == 0 ? 0UL : sizeof t_saved_mask * 8) == 0;
+    }
     if (node >= 1024)
         return false;
+    int mode = 0;
+    memset(t_saved_mask, 0, sizeof t_saved_mask);
+    if (syscall(SYS_get_mempolicy, &mode, t_saved_mask, sizeof t_saved_mask * 8, nullptr, 0UL) != 0)
+        return false;   // cannot tell what to restore: leave the policy alone
     unsigned long mask[16];
     memset(mask, 0, sizeof mask);
     mask[node / (8 * sizeof(unsigned long))] |= 1UL << (node % (8 * sizeof(unsigned long)));
-    return syscall(SYS_set_mempolicy, 1, mask, sizeof mask * 8) == 0;
+    if (syscall(SYS_set_mempolicy, 1, mask, sizeof mask * 8) != 0)
+        return false;
+    t_saved_mode = mode;   // (with its mode flags, as get_mempolicy reports them)
+    return true;
 }
 
 }  // namespace lh

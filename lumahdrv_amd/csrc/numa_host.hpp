@@ -17,7 +17,7 @@ int numa_node_of_pci(const char *sysfs_root, const char *pci_bus_id);
 bool numa_cpus_of_node(const char *sysfs_root, int node, const std::vector<int> &allowed, std::vector<int> &out);
 std::vector<int> numa_allowed_cpus();   // the process's CPUs (affinity mask of the thread-group leader)
 bool numa_pin_thread(pthread_t t, const std::vector<int> &cpus);
-// the calling thread's memory policy: MPOL_PREFERRED `node` (node < 0: back to the default policy); false when the kernel refuses
+// the calling thread's memory policy: MPOL_PREFERRED `node`; node < 0: back to the policy the thread had before; false when the kernel refuses
 bool numa_prefer_node(int node);
 
 }  // namespace lh
