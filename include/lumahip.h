@@ -297,15 +297,20 @@ int lumahip_memcpy_h2d(lumahip_ctx *ctx, void *dst_dev, const void *src_host, si
 int lumahip_memcpy_d2h(lumahip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- NUMA placement of the host side ------------------------------------------------------------------------------------
- * On a multi-socket host the context's pinned staging rings are allocated on the NUMA node of its GPU and its copy threads are
- * pinned to that node's CPUs (within the CPUs the process may use); lumahip_multi_* does the same for each shard's thread.
- * What this replaces is single-threaded (the loop at lumaenc.cpp:205-243 of the reference), so there is no reference
- * behaviour to keep.  lumahip_tune("numa", 0) switches it off; ("numa_node", N) pretends the GPU sits on node N (A/B
- * measurements, profiles/r04_numa.txt); both take effect for what is allocated / started afterwards.
- * lumahip_numa_info: info = {node of the GPU or -1 (one-node host, unknown, switched off), number of CPUs the threads are pinned
- * to, the first of them}.  lumahip_numa_pin_current_thread pins the CALLING thread the same way -- for callers that drive one
- * context per thread themselves.  lumahip_numa_plan_host is host-only (no GPU, no context): node and CPUs for a PCI bus id from
- * a sysfs tree (NULL = /sys), optionally restricted to a cpulist such as "0-63,128-191"; *ncpus = 0 when there is nothing to do. */
+ * On a multi-socket host the context's pinned staging rings are allocated on the NUMA node of its GPU.  lumahip_tune("numa", v):
+ * 0 = nothing (the behaviour before round 4); 2 (default) = the rings; 1 = the rings, and the context's copy threads -- and, in
+ * lumahip_multi_*, each shard's own thread -- pinned to that node's CPUs (within the CPUs the process may use); 3 = the threads
+ * only.  Pinning is not the default because it only pays where the process owns its cores: measured on a shared 2-socket host,
+ * staging on the wrong socket costs 5-10 % and a caller on the other socket gains 11 % on decode from rings + threads at the
+ * GPU, but pinned threads that cannot leave cores other jobs keep busy made one call in five up to 30 % slower
+ * (profiles/r04_numa.txt).  ("numa_node", N) pretends the GPU sits on node N (A/B measurements).  Both keys take effect for what
+ * is allocated / started afterwards.  What this serves replaces a single-threaded loop (lumaenc.cpp:205-243 of the reference),
+ * so there is no reference behaviour to keep.
+ * lumahip_numa_info: info = {node of the GPU or -1 (one-node host, unknown, switched off), number of that node's CPUs the
+ * process may use, the first of them}.  lumahip_numa_pin_current_thread pins the CALLING thread to them (modes 1 and 3; a no-op
+ * otherwise) -- for callers that drive one context per thread themselves.  lumahip_numa_plan_host is host-only (no GPU, no
+ * context): node and CPUs for a PCI bus id from a sysfs tree (NULL = /sys), optionally restricted to a cpulist such as
+ * "0-63,128-191"; *ncpus = 0 when there is nothing to do. */
 int lumahip_numa_info(lumahip_ctx *ctx, int info[3]);
 int lumahip_numa_pin_current_thread(lumahip_ctx *ctx);
 int lumahip_numa_plan_host(const char *sysfs_root, const char *pci_bus_id, const char *allowed_cpulist, int *node, int *cpus, int cap,

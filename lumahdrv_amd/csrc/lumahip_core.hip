@@ -267,7 +267,7 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
     } else if (k == "numa" || k == "numa_node") {
         // takes effect for what is allocated / started from now on: set it before the first host call of a context
         if (k == "numa")
-            c->numa_mode = v != 0;
+            c->numa_mode = (v >= 0 && v <= 3) ? (int)v : 2;   // 1: rings and threads, 2: the rings only (default), 3: the threads only
         else
             c->numa_force_node = v >= 0 ? (int)std::min<long>(v, 1023) : -1;
         c->numa_resolved = false;
@@ -740,7 +740,7 @@ extern "C" int lumahip_numa_pin_current_thread(lumahip_ctx *c)
         return LUMAHIP_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     numa_resolve(c);
-    if (c->numa_node >= 0 && !numa_pin_thread(pthread_self(), c->numa_cpus))
+    if (c->numa_node >= 0 && c->numa_mode != 2 && !numa_pin_thread(pthread_self(), c->numa_cpus))
         return fail(c, LUMAHIP_ERR_STATE, "pthread_setaffinity_np refused the CPUs of NUMA node %d", c->numa_node);
     return LUMAHIP_OK;
 }

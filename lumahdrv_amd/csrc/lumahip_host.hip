@@ -60,8 +60,8 @@ struct lumahip_copy_pool {
     std::atomic<int> pending{0};
     std::atomic<bool> stop{false};
 
-    // cpus: the CPUs of the GPU's NUMA node (empty: no placement) -- the workers write the pinned staging chunks, which live on
-    // that node, and read them back out of it
+    // cpus: the CPUs of the GPU's NUMA node the workers are pinned to (empty, the default: wherever the scheduler puts them;
+    // lumahip_tune "numa" 1) -- they write the pinned staging chunks, which live on that node, and read them back out of it
     lumahip_copy_pool(int n, int spin_, const std::vector<int> &cpus) : spin(spin_)   // (spin is set before the workers exist: they read it without synchronisation)
     {
         jobs.resize(n);
@@ -155,7 +155,7 @@ static void staged_copy(lumahip_ctx *c, unsigned char *dst, size_t dp, const uns
 {
     if (c->copy_threads > 0 && !c->copy_pool) {
         numa_resolve(c);
-        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin, c->numa_cpus);
+        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin, c->numa_mode == 2 ? std::vector<int>() : c->numa_cpus);
     }
     if (c->copy_pool)
         c->copy_pool->copy(dst, dp, src, sp, width, rows);
@@ -187,7 +187,7 @@ static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st, size_t bytes = XF
         // on the GPU's NUMA node: the calling thread's memory policy says where, hipHostMallocNumaUser makes the runtime follow it
         numa_resolve(c);
         bool placed = false;
-        if (c->numa_node >= 0 && numa_prefer_node(c->numa_node)) {
+        if (c->numa_node >= 0 && c->numa_mode != 3 && numa_prefer_node(c->numa_node)) {
             placed = hipHostMalloc((void **)&st.h, bytes, hipHostMallocNumaUser) == hipSuccess;
             (void)numa_prefer_node(-1);
             if (!placed) {

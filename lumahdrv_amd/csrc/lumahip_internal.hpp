@@ -140,7 +140,11 @@ struct lumahip_ctx {
     lumahip_copy_pool *copy_pool = nullptr;
     // NUMA placement of the host side (numa_host.cpp; lumahip_core.hip numa_resolve): the node of this context's GPU and that
     // node's CPUs.  The pinned staging rings are allocated on the node and the copy threads are pinned to its CPUs.
-    int numa_mode = 1;         // lumahip_tune("numa", 0): no placement, as before round 4
+    // lumahip_tune("numa", v): 0 = no placement, as before round 4; 2 (default) = the rings on the GPU's node, the threads left
+    // to the scheduler; 1 = rings and threads; 3 = threads only.  Why not 1 by default: on the shared hosts of the GPU boxes
+    // (load average 16-33) pinned copy threads cannot move away from cores other tenants keep busy, and the one-frame and
+    // pipelined facade calls then dip by up to 30 % every few runs (profiles/r04_numa.txt, second table)
+    int numa_mode = 2;
     int numa_force_node = -1;  // lumahip_tune("numa_node", N): pretend the GPU sits on node N (A/B measurements: local against remote)
     bool numa_resolved = false;
     int numa_node = -1;        // -1: not a NUMA box / unknown / switched off

@@ -75,9 +75,8 @@ def main():
 
             def run():
                 c = L.Context(0)
-                if S == "off":
-                    c.tune("numa", 0)
-                elif S != "auto":
+                c.tune("numa", 0 if S == "off" else 1)          # 1 = rings AND pinned copy threads (the library's default is rings only)
+                if isinstance(S, int):
                     c.tune("numa_node", S)
                 c.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, lut)
                 fp = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
