@@ -492,3 +492,41 @@ def test_sync_and_host_calls_inside_an_unordered_section(oracle_mod):
     for p in d_pl:
         c.free(p)
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_numa_placement_modes_do_not_change_results(oracle_mod, mode):
+    """lumahip_tune numa 0 / 1 / 2 / 3 (nothing / rings + pinned copy threads / rings only, the default / threads only): where
+    the pinned staging rings live and where the copy threads run changes no byte of a host-fed batch; lumahip_numa_info reports
+    a node of this host (or -1 on a one-node host) and lumahip_numa_pin_current_thread leaves the caller inside that node."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    cfg = (L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005)
+    c = L.Context(0)
+    c.tune("numa", mode)
+    c.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+    info = c.numa_info()
+    nodes = [d for d in os.listdir("/sys/devices/system/node")] if os.path.isdir("/sys/devices/system/node") else []
+    nnodes = len([d for d in nodes if d.startswith("node") and d[4:].isdigit()])
+    if mode == 0 or nnodes < 2:
+        assert info["node"] == -1 and info["cpus"] == 0
+    else:
+        assert 0 <= info["node"] < nnodes and info["cpus"] > 0
+    orc = o.Oracle(*cfg)
+    frames = [o.synth_frame(1920, 1080, 3, i) for i in range(5)]          # large enough for the copy threads to be used
+    planes, st, _ = c.encode_frames(frames, 1.0, 2)
+    for f, pl in zip(frames, planes):
+        e, _, _ = orc.encode(f.copy(), 1.0, 2, threads=4)
+        assert all(np.array_equal(a, b) for a, b in zip(pl, e))
+    dec = c.decode_frames(planes, st, 1920, 1080, 1.0, 2)
+    assert np.array_equal(dec[0].view(np.uint32), orc.decode(planes[0], st, 1920, 1080, 1.0, 2, threads=4).view(np.uint32))
+    before = os.sched_getaffinity(0)
+    assert c.L.lumahip_numa_pin_current_thread(c.h) == 0
+    after = os.sched_getaffinity(0)
+    if mode in (1, 3) and info["node"] >= 0:
+        assert len(after) == info["cpus"] and after <= before
+    else:
+        assert after == before
+    os.sched_setaffinity(0, before)
+    c.close()
