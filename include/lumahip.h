@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LUMAHIP_ABI_VERSION 2
+#define LUMAHIP_ABI_VERSION 3   /* 3: round-4 additions (value_host scalar forms, half-input table, NUMA, multi transport); nothing removed or changed */
 
 enum lumahip_status {
     LUMAHIP_OK = 0,
