@@ -530,3 +530,41 @@ def test_numa_placement_modes_do_not_change_results(oracle_mod, mode):
         assert after == before
     os.sched_setaffinity(0, before)
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sc", [1.0, 20.0, 65536.0, 65537.0, 1e6, 1.0 / 65536.0, 1e-6, 3e38])
+def test_ycbcr_decode_prescalings_inside_and_outside_the_short_division_range(oracle_mod, sc):
+    """The YCbCr decode kernels divide by preScaling with a 5-operation quotient when sc is in [2^-16, 2^16] (two copies of the
+    unit's code, chosen per launch) and send everything else -- and every value the exponent guard turns away -- to the complete
+    functions with IEEE division: decoded floats 0 ulp against the oracle on both sides of both limits, random codes plus the
+    darkest ones (where the decoded value underflows the guard)."""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    cfg = (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01)
+    q = L.LumaQuantizer()
+    q.setQuantizer(*cfg)
+    orc = o.Oracle(*cfg)
+    rng = np.random.default_rng(int(np.float32(sc).view(np.uint32)))
+    for profile, (w, h) in ((2, (256, 64)), (3, (128, 32)), (0, (64, 16))):
+        _, hs, st, bps = L.plane_geometry(w, h, profile)
+        ws = (w, w // 2 if profile in (0, 2) else w, w // 2 if profile in (0, 2) else w)
+        planes = []
+        for p in range(3):
+            hi = 256 if bps == 1 else 1030
+            codes = rng.integers(0, hi, size=(hs[p], ws[p]))
+            if p == 0:
+                codes[0, :] = rng.integers(0, 6, size=ws[p])        # the darkest luminance codes
+            else:
+                codes[:2, :] = rng.integers(500, 530, size=(2, ws[p]))   # near-neutral chroma: sums that cancel
+            buf = np.zeros((hs[p], st[p]), dtype=np.uint8)
+            if bps == 2:
+                buf[:, :2 * ws[p]] = codes.astype("<u2").view(np.uint8).reshape(hs[p], 2 * ws[p])
+            else:
+                buf[:, :ws[p]] = codes.astype(np.uint8)
+            planes.append(buf)
+        got = q.ctx.decode_frame(planes, st, w, h, sc, profile)
+        with np.errstate(all="ignore"):
+            exp = orc.decode(planes, st, w, h, sc, profile)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        assert bool(same.all()), (sc, profile, np.argwhere(~same)[:4].tolist())
