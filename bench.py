@@ -447,6 +447,20 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                             float(np.median(diso)) if diso else None, dprobe_ms, "decode_hbm_bytes_per_launch", dkname)
         dec_blk["output_layout"] = r["decode_output_layout"]
         mix = load_profile(os.path.join(args.profile_dir, "valu_mix_latest.json"), name, px_step, sha)
+        def valu_block(m, ms, hbm_blk):
+            """VALU-issue roofline of a YCbCr kernel from the PMC instruction mix of these kernel sources (None without one)"""
+            peak = N_SIMD * CLOCK_GHZ
+            blk = {"bound": "valu", "achieved": None, "peak": round(peak, 1), "unit": "G SIMD-issue-cycles/s", "frac": None, "hbm": hbm_blk}
+            if m:
+                cyc = m["issue_cycles_per_launch"] * (px_step / m["pixels_per_launch"])
+                ach = cyc / (ms * 1e-3) / 1e9
+                blk.update({"achieved": round(ach, 1), "frac": round(ach / peak, 4), "valu_instructions_per_pixel": m.get("valu_per_pixel"),
+                            "fp64_instructions_per_pixel": m.get("fp64_per_pixel"),
+                            "frac_is": "PMC class counters x measured issue costs / kernel time, against 1024 SIMDs x 2.4 GHz (nominal clock)"})
+            else:
+                blk["note"] = "no instruction-mix capture of the current kernel sources in profiles/"
+            return blk
+        dec_ms_own = (tdo["dev_ms_median"] if tdo else td["dev_ms_median"]) / K
         half = ctx.half_table_info(sc) if cs == 2 else None
         if cs == 2 and half["used"] and half["table_launches"] > 0 and half["backoff_launches"] == 0:
             # YCbCr encode on the half-input table (the synthetic stream, like every EXR frame of the reference, holds binary16
@@ -459,7 +473,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 r["roofline"]["valu_instructions_per_pixel"] = mix.get("valu_per_pixel")
                 r["roofline"]["fp64_instructions_per_pixel"] = mix.get("fp64_per_pixel")
             r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]
-            r["decode_roofline"] = {"bound": "valu", "hbm": dec_blk}
+            r["decode_roofline"] = valu_block(mix.get("decode") if mix else None, dec_ms_own, dec_blk)
         elif cs == 2:
             # YCbCr without the table: VALU-issue-bound.  Issue cycles per pixel = sum over instruction classes of (PMC instruction count x
             # issue cost measured by tools/bench/valu_bench.hip: fp32 / int32 2 cycles per wave64 instruction, fp64 4,
@@ -479,7 +493,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 r["roofline"] = dict({"bound": "valu", "achieved": None, "peak": round(peak, 1), "unit": "G SIMD-issue-cycles/s",
                                       "frac": None, "note": "no instruction-mix capture of the current kernel sources in profiles/",
                                       "hbm": hbm}, **common)
-            r["decode_roofline"] = {"bound": "valu", "hbm": dec_blk}
+            r["decode_roofline"] = valu_block(mix.get("decode") if mix else None, dec_ms_own, dec_blk)
         else:
             r["roofline"] = enc_blk
             r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]

@@ -201,4 +201,6 @@ def test_bench_config3_encode_is_hbm_bound():
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["frac"] > 0.5 and r["value"] > 250000, (rf["frac"], r["value"])
     assert rf["half_input_table"]["table_launches"] > 0 and rf["half_input_table"]["backoff_launches"] == 0
-    assert r["decode_roofline"]["bound"] == "valu"
+    dr = r["decode_roofline"]
+    assert dr["bound"] == "valu" and dr["hbm"]["frac"] > 0.15
+    assert dr["frac"] is None or 0.3 < dr["frac"] < 1.05      # (VALU roofline from the committed instruction mix, when it matches the sources)
