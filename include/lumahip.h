@@ -75,12 +75,13 @@ int lumahip_sync(lumahip_ctx *ctx);
  * records), "allow_aliased_frames" (1: the layout check accepts batches whose frames overlap), "lanes" (default lane
  * count of lumahip_begin_unordered), "lane_grid_enc" / "lane_grid_dec" (workgroups per launch inside an unordered section,
  * 0 = rule), "copy_threads" (worker threads that copy pageable caller memory into the pinned staging chunks of the _host
- * entry points: 0..32, default 3), "host_bands" (row bands the single-frame _host entry points split a frame into so that
+ * entry points: 0..32, default 5), "host_bands" (row bands the single-frame _host entry points split a frame into so that
  * the upload of band k+1, the kernel of band k and the download of band k-1 overlap: 1..8, default 4), "band_taper" (each band's rows in
  * per cent of the previous band's, 10..100, default 70: the last band is small, so little is left to do once the upload ends), "ycbcr_tables" (0: the
  * YCbCr kernels evaluate every PQ function per pixel instead of taking the luminance code / the luma from per-stream tables),
  * "half_table" (0 / 1 / 2: when the YCbCr encode kernels use the half-input table, see lumahip_ycbcr_half_table_host),
- * "numa" / "numa_node" (NUMA placement of the staging rings and copy threads, see lumahip_numa_info).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
+ * "numa" / "numa_node" (NUMA placement of the staging rings and copy threads, see lumahip_numa_info),
+ * "half_upload" (0 / 1 / 2: whether host frames that hold binary16 values cross PCIe as halves, see lumahip_half_upload_info).  The environment variables LUMAHIP_BLOCK, LUMAHIP_BLOCKS_PER_CU, LUMAHIP_GRID_ENC,
  * LUMAHIP_GRID_DEC, LUMAHIP_LDS_TABLE_MAX_KB, LUMAHIP_FORCE_LITERAL, LUMAHIP_ALLOW_ALIASED_FRAMES, LUMAHIP_LANES, LUMAHIP_LANE_GRID_ENC,
  * LUMAHIP_LANE_GRID_DEC, LUMAHIP_COPY_THREADS, LUMAHIP_HOST_BANDS, LUMAHIP_BAND_TAPER, LUMAHIP_YCBCR_TABLES, LUMAHIP_HALF_TABLE set the
  * same keys when a context is created, but only if LUMAHIP_TUNING=1 is set as well. */
@@ -295,6 +296,20 @@ int lumahip_malloc(lumahip_ctx *ctx, void **dev_ptr, size_t bytes);
 int lumahip_free(lumahip_ctx *ctx, void *dev_ptr);
 int lumahip_memcpy_h2d(lumahip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int lumahip_memcpy_d2h(lumahip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- Half upload of the host encode entry points -------------------------------------------------------------------------
+ * The reference's LumaFrame is float, but the frames its EXR reader produces hold binary16 values widened to float
+ * (src/exr_interface.cpp:77-146).  lumahip_encode_frame_host, lumahip_encode_frames_host and lumahip_encode_stream_push -- and so
+ * LumaEncoder::encode(LumaFrame *) -- send such a frame over PCIe as halves (6 instead of 12 bytes per pixel): the copy threads
+ * convert while they stage and check every value's round trip, the encode kernels widen the halves back exactly, and the planes
+ * are those of the float upload bit for bit.  A frame (or row band) that holds anything else goes up as floats as before; after
+ * one such frame the next 16 are not tried (the pause doubling up to 1024 while it keeps happening), so a stream of
+ * full-precision floats pays nothing.  Needs F16C on the host CPU, rows of a multiple of 4 pixels and the luminance records
+ * in LDS (every table up to 13 bits); not used when the caller asks for the transformed float frame back.
+ * lumahip_tune("half_upload", 0 | 1 | 2) = never / as described (default) / always try.
+ * lumahip_half_upload_info: info = {frames (or row bands) uploaded as halves, frames found to hold other values, frames left in
+ * the current pause}. */
+int lumahip_half_upload_info(const lumahip_ctx *ctx, long info[3]);
 
 /* ---- NUMA placement of the host side ------------------------------------------------------------------------------------
  * On a multi-socket host the context's pinned staging rings are allocated on the NUMA node of its GPU.  lumahip_tune("numa", v):

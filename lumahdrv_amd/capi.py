@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_numa_info", "lumahip_numa_pin_current_thread", "lumahip_numa_plan_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_half_upload_info", "lumahip_numa_info", "lumahip_numa_pin_current_thread", "lumahip_numa_plan_host", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
     "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
@@ -125,6 +125,7 @@ def lib():
     L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
     L.lumahip_ycbcr_half_table_host.argtypes = [f, f, vp, sz]
     L.lumahip_half_table_info.argtypes = [vp, f, C.POINTER(i)]
+    L.lumahip_half_upload_info.argtypes = [vp, C.POINTER(C.c_long)]
     L.lumahip_numa_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_numa_pin_current_thread.argtypes = [vp]
     L.lumahip_numa_plan_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(i), C.POINTER(i), i, C.POINTER(i)]
@@ -392,6 +393,11 @@ class Context:
         a = (C.c_int * 5)()
         self._chk(self.L.lumahip_quantizer_info(self.h, a))
         return dict(mode=a[0], mant_bits=a[1], buckets=a[2], shift=a[3], lds_bytes=a[4])
+
+    def half_upload_info(self):
+        a = (C.c_long * 3)()
+        self._chk(self.L.lumahip_half_upload_info(self.h, a))
+        return dict(half_frames=a[0], float_fallbacks=a[1], pause_left=a[2])
 
     def numa_info(self):
         a = (C.c_int * 3)()

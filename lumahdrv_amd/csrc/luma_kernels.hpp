@@ -290,6 +290,21 @@ LH_DEV void load_px(const float *p, float (&v)[VW])
     }
 }
 
+// the same VW pixels from a frame uploaded as binary16 (the host entry points' half upload, lumahip_host.hip): exact widening
+template <int VW>
+LH_DEV void load_px_h(const _Float16 *p, float (&v)[VW])
+{
+    typedef _Float16 lh_v4h __attribute__((ext_vector_type(4)));
+    typedef _Float16 lh_v2h __attribute__((ext_vector_type(2)));
+    if constexpr (VW == 4) {
+        const lh_v4h t = __builtin_nontemporal_load(reinterpret_cast<const lh_v4h *>(p));
+        v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+    } else {
+        const lh_v2h t = __builtin_nontemporal_load(reinterpret_cast<const lh_v2h *>(p));
+        v[0] = (float)t.x; v[1] = (float)t.y;
+    }
+}
+
 template <int VW>
 LH_DEV void store_px(float *p, const float (&v)[VW])
 {
@@ -327,7 +342,8 @@ struct EncUnit {
     bool valid;
 };
 
-template <int VW>
+// IN16: the frames are binary16 (a.src[c] points at halves; offsets and strides count elements either way)
+template <int VW, bool IN16 = false>
 LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, int NW)
 {
     u.valid = false;
@@ -343,8 +359,14 @@ LH_DEV void enc_load(EncUnit<VW> &u, const EncArgs &a, int t, int tx, int ty, in
     const size_t off = (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        load_px<VW>(a.src[c] + off, u.in[c][0]);
-        load_px<VW>(a.src[c] + off + a.g.w, u.in[c][1]);
+        if constexpr (IN16) {
+            const _Float16 *hp = reinterpret_cast<const _Float16 *>(a.src[c]);
+            load_px_h<VW>(hp + off, u.in[c][0]);
+            load_px_h<VW>(hp + off + a.g.w, u.in[c][1]);
+        } else {
+            load_px<VW>(a.src[c] + off, u.in[c][0]);
+            load_px<VW>(a.src[c] + off + a.g.w, u.in[c][1]);
+        }
     }
 }
 
@@ -531,7 +553,7 @@ LH_DEV void enc_emit(int f, int ux, int uy, const float (&c0)[2 * VW], const flo
     }
 }
 
-template <int CS, bool SUB, int VW, int LM>
+template <int CS, bool SUB, int VW, int LM, bool IN16 = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<CS, SUB, VW>::value))) void k_encode(const EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     // stores first the write bursts of a wave are not queued behind its own 6 KiB of reads.
     EncUnit<VW> u;
     int n_units = 0, n_general = 0;   // HALF: this wave's units, and those in which some lane left the table (wave-uniform)
-    enc_load<VW>(u, a, blockIdx.x, tx, ty, NW);
+    enc_load<VW, IN16>(u, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
         if (a.stats) {
             const int f = t / a.g.tilesPerFrame;  // wave-uniform
@@ -597,7 +619,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
             else
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, s_rec);
         }
-        enc_load<VW>(u, a, t + G, tx, ty, NW);
+        enc_load<VW, IN16>(u, a, t + G, tx, ty, NW);
     }
     if (a.stats)
         stats_flush(st, a.stats, tx);
@@ -932,7 +954,7 @@ __global__ __launch_bounds__(256) void k_transform(const XfArgs a)
 // needs the reference's value -- the host entry points do when the fast mean is within 1 % of the threshold -- these two
 // kernels reproduce it: k_channel0 writes the transformed channel 0 of one frame, k_seq_sum adds it up in the reference's
 // order (one wave; lanes load 64 consecutive values at a time, the adds run lane-uniformly in raster order; ~25 ms at 4K).
-template <int CS>
+template <int CS, bool IN16 = false>
 __global__ __launch_bounds__(256) void k_channel0(const float *src, size_t chan_stride, size_t n, float sc, float Lmax, float *out)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[CS == CS_YCBCR ? sizeof(PowfTablesWide) : 16];
@@ -944,7 +966,18 @@ __global__ __launch_bounds__(256) void k_channel0(const float *src, size_t chan_
     const XformConst k = make_xform_const<CS>(sc, Lmax, &s_pw);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float c0, c1, c2;
-        xform_fwd<CS>(src[i] * sc, src[i + chan_stride] * sc, src[i + 2 * chan_stride] * sc, k, c0, c1, c2);
+        float r, g, b;
+        if constexpr (IN16) {   // the frame was uploaded as binary16
+            const _Float16 *hp = reinterpret_cast<const _Float16 *>(src);
+            r = (float)hp[i];
+            g = (float)hp[i + chan_stride];
+            b = (float)hp[i + 2 * chan_stride];
+        } else {
+            r = src[i];
+            g = src[i + chan_stride];
+            b = src[i + 2 * chan_stride];
+        }
+        xform_fwd<CS>(r * sc, g * sc, b * sc, k, c0, c1, c2);
         out[i] = c0;
     }
 }

@@ -68,7 +68,7 @@ extern "C" int lumahip_create(lumahip_ctx **out, int device)
                                               {"LUMAHIP_FORCE_LITERAL", "force_literal"}, {"LUMAHIP_LANES", "lanes"},
                                               {"LUMAHIP_LANE_GRID_ENC", "lane_grid_enc"}, {"LUMAHIP_LANE_GRID_DEC", "lane_grid_dec"},
                                               {"LUMAHIP_COPY_THREADS", "copy_threads"}, {"LUMAHIP_HOST_BANDS", "host_bands"}, {"LUMAHIP_BAND_TAPER", "band_taper"}, {"LUMAHIP_COPY_SPIN", "copy_spin"},
-                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}, {"LUMAHIP_HALF_TABLE", "half_table"}, {"LUMAHIP_NUMA", "numa"}, {"LUMAHIP_NUMA_NODE", "numa_node"}};
+                                              {"LUMAHIP_YCBCR_TABLES", "ycbcr_tables"}, {"LUMAHIP_HALF_TABLE", "half_table"}, {"LUMAHIP_NUMA", "numa"}, {"LUMAHIP_NUMA_NODE", "numa_node"}, {"LUMAHIP_HALF_UPLOAD", "half_upload"}};
         for (const auto &k : keys)
             if (const char *e = getenv(k[0]))
                 (void)lumahip_tune(c, k[1], atol(e));
@@ -273,6 +273,11 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->numa_resolved = false;
         lumahip_copy_pool_destroy(c->copy_pool);
         c->copy_pool = nullptr;
+    } else if (k == "half_upload") {
+        if (v < 0 || v > 2)
+            return fail(c, LUMAHIP_ERR_ARG, "half_upload must be 0 (never), 1 (while the frames hold binary16 values) or 2 (always try)");
+        c->in16_mode = (int)v;
+        c->in16_backoff = c->in16_backoff_len = 0;
     } else if (k == "half_table") {
         if (v < 0 || v > 2)
             return fail(c, LUMAHIP_ERR_ARG, "half_table must be 0 (off), 1 (while the stream is binary16 data) or 2 (always)");
@@ -720,6 +725,16 @@ void numa_resolve(lumahip_ctx *c)
         return;   // (e.g. a cpuset that excludes the whole node: leave the threads where the scheduler puts them)
     c->numa_node = node;
     c->numa_cpus = cpus;
+}
+
+extern "C" int lumahip_half_upload_info(const lumahip_ctx *c, long info[3])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    info[0] = (long)c->in16_frames;
+    info[1] = (long)c->in16_fallbacks;
+    info[2] = c->in16_backoff;
+    return LUMAHIP_OK;
 }
 
 extern "C" int lumahip_numa_info(lumahip_ctx *c, int info[3])

@@ -60,6 +60,18 @@ static enc_kernel_t pick_enc2(int vw, int mode)
     return k_encode<CS, SUB, 2, 2>;
 }
 
+// binary16 frames: the records-in-LDS kernels at four pixels per thread only (what the host entry points' half upload needs)
+static enc_kernel_t pick_enc_in16(int cs, bool sub)
+{
+    switch (cs) {
+    case CS_LUV: return sub ? k_encode<CS_LUV, true, 4, 3, true> : k_encode<CS_LUV, false, 4, 3, true>;
+    case CS_RGB: return sub ? k_encode<CS_RGB, true, 4, 3, true> : k_encode<CS_RGB, false, 4, 3, true>;
+    case CS_YCBCR: return sub ? k_encode<CS_YCBCR, true, 4, 3, true> : k_encode<CS_YCBCR, false, 4, 3, true>;
+    case CS_XYZ: return sub ? k_encode<CS_XYZ, true, 4, 3, true> : k_encode<CS_XYZ, false, 4, 3, true>;
+    }
+    return nullptr;   // (CS_PACK: frames that are already colour-transformed do not hold halves; never asked for)
+}
+
 static enc_kernel_t pick_enc(int cs, bool sub, int vw, int mode)
 {
     switch (cs) {
@@ -105,14 +117,15 @@ namespace lhost {
 
 int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
                               unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
-                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes)
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes, bool in16)
 {
     if (!c || !rgb || !rgb[0] || !rgb[1] || !rgb[2] || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
-    if ((rc = check_layout(c, w, h, profile, nframes, rgb, frame_stride, stride, pfs)))
+    // (binary16 frames come from this library's own staging code: the overlap test of the float planes, which measures in floats, is skipped)
+    if ((rc = check_layout(c, w, h, profile, nframes, in16 ? nullptr : rgb, frame_stride, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_search_index(c)))
@@ -125,8 +138,13 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     int vw = (fast_search && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb[0], 8) || !is_aligned(rgb[1], 8) || !is_aligned(rgb[2], 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
+    if (in16) {   // halves: 8-byte loads of four pixels
+        if (mode != LUT_THRESH_LDS || (w % 4) != 0 || (frame_stride % 4) != 0)
+            return fail(c, LUMAHIP_ERR_UNSUPPORTED, "binary16 frames need the luminance records in LDS and rows of a multiple of 4 pixels");
+        vw = 4;
+    }
     // YCbCr without per-frame statistics (they need the luminance itself): the luminance code comes straight from the luma
-    const bool ycode = cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
+    const bool ycode = !in16 && cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
     // ... and R', G', B' of binary16 inputs from the half-input table of this call's (sc, Lmax), when table + records fit the LDS
     const float *half = nullptr;
     if (ycode && c->half_mode != 0 && lds_bytes(c, true, cs_eff, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
@@ -166,7 +184,9 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
             a.aligned = 0;
     }
     a.q.cs = cs_eff;
-    enc_kernel_t kern = pick_enc(cs_eff, sub, vw, half ? 6 : ycode ? 5 : mode);
+    enc_kernel_t kern = in16 ? pick_enc_in16(cs_eff, sub) : pick_enc(cs_eff, sub, vw, half ? 6 : ycode ? 5 : mode);
+    if (!kern)
+        return fail(c, LUMAHIP_ERR_UNSUPPORTED, "no encode kernel for colour space %d%s", cs_eff, in16 ? " with binary16 frames" : "");
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = grid_for(c, threads, a.g.totalTiles, 0, 0, half ? 2 : cs_eff == CS_YCBCR ? 1 : 0);
@@ -194,6 +214,11 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         hipLaunchKernelGGL(k_fold_stats, dim3((nframes + 63) / 64), dim3(64), 0, s, c->d_stats_part, stats, (int)nframes);
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
+}
+
+bool encode_supports_in16(lumahip_ctx *c, unsigned w)
+{
+    return ensure_search_index(c) == LUMAHIP_OK && c->q.mode == LUT_THRESH_LDS && (w % 4) == 0;
 }
 
 }  // namespace lhost

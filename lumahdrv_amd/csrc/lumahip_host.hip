@@ -1,6 +1,7 @@
 // lumahip_host.hip -- the _host entry points of include/lumahip.h: staging buffers, host <-> device transfers, the 3-slot
 // pipeline of the batched forms.  No kernels here.
 #include "lumahip_internal.hpp"
+#include "half_stage.hpp"
 
 #include <atomic>
 #include <condition_variable>
@@ -18,6 +19,15 @@ static int encode_packed(lumahip_ctx *c, const float *rgb, size_t frame_stride, 
     const size_t n = (size_t)w * h;
     const float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
     return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs, false);
+}
+// the same for a frame that was uploaded as binary16 (xfer_h2d_f16): planes at the same element offsets behind a pointer to halves
+static int encode_packed16(lumahip_ctx *c, const void *halves, size_t frame_stride, unsigned nframes, unsigned w, unsigned h, float sc,
+                           int profile, unsigned char *const planes[3], const int stride[3], const size_t pfs[3], float *stats)
+{
+    const size_t n = (size_t)w * h;
+    const uint16_t *b = static_cast<const uint16_t *>(halves);
+    const float *const pl[3] = {reinterpret_cast<const float *>(b), reinterpret_cast<const float *>(b + n), reinterpret_cast<const float *>(b + 2 * n)};
+    return encode_frames_device_impl(c, pl, frame_stride, nframes, w, h, sc, profile, planes, stride, pfs, stats, c->q.cs, false, true);
 }
 static int decode_packed(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                          unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *rgb, size_t frame_stride)
@@ -40,14 +50,16 @@ static constexpr size_t XFER_CHUNK = (size_t)8 << 20;
 // ---- copy threads ---------------------------------------------------------------------------------------------------------
 // One CPU thread copies pageable memory into a pinned chunk at ~21 GB/s on the GPU box's host, a third of what the PCIe
 // link moves (profiles/r02_hostfed.txt: 1.4 Gpixel/s pageable against 4.2 pinned).  The staging copies are therefore split
-// over a few persistent worker threads owned by the context (lumahip_tune "copy_threads", default 4; 0 = the calling thread
+// over a few persistent worker threads owned by the context (lumahip_tune "copy_threads", default 5; 0 = the calling thread
 // alone): the CPU side then keeps up with the DMA of the previous chunk.
 struct lumahip_copy_pool {
     struct Job {
         unsigned char *dst;
         const unsigned char *src;
         size_t width, rows, dst_pitch, src_pitch;  // rows x width bytes; rows == 1: one flat span
+        bool to_half = false;                      // flat span of `width` bytes of floats -> width / 2 bytes of halves (half_stage.cpp)
     };
+    std::atomic<bool> inexact{false};   // a to_half job met a value that is not a half (raised by any worker, read by copy_to_half)
     // A worker that has just finished a piece polls for the next one for ~0.5 ms before it goes to sleep on the condition
     // variable: while a frame streams through, the pieces follow each other within tens of microseconds, and waking a
     // sleeping thread costs 50-100 us on the GPU box's host -- as much as copying the piece (a 4K band is 8 MB).
@@ -81,6 +93,15 @@ struct lumahip_copy_pool {
         for (auto &t : workers)
             t.join();
     }
+    void run_job(const Job &j)
+    {
+        if (j.to_half) {
+            if (!lh::convert_f32_to_f16_checked(reinterpret_cast<const float *>(j.src), reinterpret_cast<uint16_t *>(j.dst), j.width / 4))
+                inexact.store(true, std::memory_order_relaxed);
+            return;
+        }
+        run(j);
+    }
     static void run(const Job &j)
     {
         if (j.rows == 1) {
@@ -109,7 +130,7 @@ struct lumahip_copy_pool {
             seen = g;
             const Job j = jobs[me];
             if (j.width)
-                run(j);
+                run_job(j);
             pending.fetch_sub(1, std::memory_order_release);
         }
     }
@@ -146,6 +167,42 @@ struct lumahip_copy_pool {
             run(mine);
         while (pending.load(std::memory_order_acquire) != 0)
             __builtin_ia32_pause();
+    }
+    // n floats at src -> n halves at dst, split over the workers and the calling thread (spans cut at multiples of 2048 floats);
+    // false when some value is not a half (dst is then useless)
+    bool copy_to_half(uint16_t *dst, const float *src, size_t n)
+    {
+        inexact.store(false, std::memory_order_relaxed);
+        const size_t parts = workers.size() + 1;
+        if (n < ((size_t)64 << 10) || n < parts)
+            return lh::convert_f32_to_f16_checked(src, dst, n);
+        size_t per = ((n + parts - 1) / parts + 2047) & ~(size_t)2047;
+        auto part = [&](size_t k) -> Job {
+            const size_t a = std::min(n, k * per), b = std::min(n, (k + 1) * per);
+            Job j{nullptr, nullptr, 0, 0, 0, 0};
+            if (a < b) {
+                j.dst = reinterpret_cast<unsigned char *>(dst + a);
+                j.src = reinterpret_cast<const unsigned char *>(src + a);
+                j.width = (b - a) * 4;
+                j.rows = 1;
+                j.to_half = true;
+            }
+            return j;
+        };
+        for (size_t k = 0; k < workers.size(); k++)
+            jobs[k] = part(k + 1);
+        pending.store((int)workers.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv_go.notify_all();
+        const Job mine = part(0);
+        if (mine.width)
+            run_job(mine);
+        while (pending.load(std::memory_order_acquire) != 0)
+            __builtin_ia32_pause();
+        return !inexact.load(std::memory_order_relaxed);
     }
 };
 
@@ -368,6 +425,68 @@ int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream
 
 }
 
+// Host floats -> device halves: the half upload.  The reference's LumaFrame is float, but its EXR reader fills it with widened
+// binary16 values (src/exr_interface.cpp:77-146); such a frame crosses PCIe in 6 instead of 12 bytes per pixel, and the encode
+// kernels instantiated for binary16 input (k_encode<., ., 4, 3, IN16>) widen it back exactly.  The copy threads convert while
+// they stage (reading 12 B and writing 6 B per pixel moves less memory than the plain staging copy) and check every value's
+// round trip; *exact = false as soon as a chunk holds anything that is not a half -- nothing of that chunk has been queued then,
+// and the caller uploads the frame (or band) as floats instead.  Pinned or pageable `src` alike: the CPU reads it either way.
+static int xfer_h2d_f16(lumahip_ctx *c, void *dst_halves, const float *src, size_t nfloats, hipStream_t s, bool *exact)
+{
+    *exact = true;
+    if (c->copy_threads > 0 && !c->copy_pool) {
+        numa_resolve(c);
+        c->copy_pool = new lumahip_copy_pool(c->copy_threads, c->copy_spin, c->numa_mode == 2 ? std::vector<int>() : c->numa_cpus);
+    }
+    for (size_t done = 0; done < nfloats;) {
+        lumahip_ctx::Stage &st = c->stage_up[c->up_next++ % lumahip_ctx::N_STAGE];
+        if (int rc = stage_ready(c, st))
+            return rc;
+        size_t cap = XFER_CHUNK;   // bytes of halves per chunk; the first chunks of a call are small (see xfer_h2d_2d)
+        if (c->up_ramp < 3)
+            cap = std::min(cap, (size_t)1 << (20 + c->up_ramp++));
+        const size_t n = std::min(nfloats - done, cap / 2);
+        const bool ok = c->copy_pool ? c->copy_pool->copy_to_half(reinterpret_cast<uint16_t *>(st.h), src + done, n)
+                                     : lh::convert_f32_to_f16_checked(src + done, reinterpret_cast<uint16_t *>(st.h), n);
+        if (!ok) {
+            *exact = false;
+            return LUMAHIP_OK;
+        }
+        HIPCHK(c, hipMemcpyAsync((unsigned char *)dst_halves + done * 2, st.h, n * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(st.ev, s));
+        st.pending = true;
+        done += n;
+    }
+    return LUMAHIP_OK;
+}
+
+// Whether this call tries the half upload (lumahip_tune "half_upload": 0 never, 1 while the frames hold halves, 2 always try).
+// A frame that turns out to hold other values costs the conversion of its first chunks for nothing, so after one such frame
+// the next 16 go up as floats before one is tried again, the pause doubling up to 1024 frames while the misses continue.
+static bool in16_try(lumahip_ctx *c, unsigned w, bool wants_float_frame)
+{
+    if (c->in16_mode == 0 || wants_float_frame || !lh::f16c_available() || !encode_supports_in16(c, w))
+        return false;
+    if (c->in16_mode == 2)
+        return true;
+    if (c->in16_backoff > 0) {
+        c->in16_backoff--;
+        return false;
+    }
+    return true;
+}
+static void in16_result(lumahip_ctx *c, bool exact)
+{
+    if (exact) {
+        c->in16_frames++;
+        c->in16_backoff_len = 0;
+    } else {
+        c->in16_fallbacks++;
+        c->in16_backoff_len = c->in16_backoff_len ? std::min(2 * c->in16_backoff_len, 1024) : 16;
+        c->in16_backoff = c->in16_backoff_len;
+    }
+}
+
 // Device -> host.  Pinned destination: queued on `s`, the caller synchronises.  Pageable destination: the data goes through
 // the ring of pinned chunks; with `deferred` false it is in `dst` when the call returns (everything queued on `s` before it has
 // completed by then), with `deferred` true the last chunks may still be in flight and d2h_flush() completes them -- which lets
@@ -578,6 +697,11 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
     unsigned band0[lumahip_ctx::MAX_BANDS + 1];
     const int nb = band_plan(c, w, h, band0);
     float st[3] = {0.0f, __builtin_inff(), -__builtin_inff()};
+    // Half upload (xfer_h2d_f16): tried unless the caller wants the transformed FLOAT frame back.  frame16: every band so far went
+    // up as halves; mixed: some did and then a band held other values -- the device frame is then not usable as a whole.
+    // (nor for frames that are already colour-transformed -- lumahip_pack_frame_host: such values are never halves)
+    bool use16 = in16_try(c, w, transformed_out != nullptr || cs_eff == CS_PACK), frame16 = use16, mixed = false;
+    const bool tried16 = use16;
     if (nb > 1) {
         if ((rc = pipe_streams(c)) || (rc = band_events(c, nb)))
             return rc;
@@ -598,18 +722,38 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         for (int k = 0; k < nb && rc == LUMAHIP_OK; k++) {
             const unsigned r0 = band0[k], rows = band0[k + 1] - r0;
             const size_t roff = (size_t)r0 * w;
-            for (int ch = 0; ch < 3 && rc == LUMAHIP_OK; ch++)
-                rc = xfer_h2d(c, c->d_frame + ch * n1 + roff, rgb + ch * n1 + roff, (size_t)rows * w * sizeof(float), c->s_h2d);
-            if (rc)
-                break;
+            uint16_t *const d16 = reinterpret_cast<uint16_t *>(c->d_frame);
+            if (use16) {
+                bool exact = true;
+                for (int ch = 0; ch < 3 && rc == LUMAHIP_OK && exact; ch++)
+                    rc = xfer_h2d_f16(c, d16 + ch * n1 + roff, rgb + ch * n1 + roff, (size_t)rows * w, c->s_h2d, &exact);
+                if (rc)
+                    break;
+                if (!exact) {
+                    // this band holds values that are not halves: it and the rest of the frame go up as floats -- into the same
+                    // buffer, at float offsets, which the kernels of the earlier bands may still be reading as halves: wait for them
+                    use16 = frame16 = false;
+                    mixed = k > 0;
+                    HIPCHK(c, hipStreamSynchronize(c->s_kern));
+                }
+            }
+            if (!use16) {
+                for (int ch = 0; ch < 3 && rc == LUMAHIP_OK; ch++)
+                    rc = xfer_h2d(c, c->d_frame + ch * n1 + roff, rgb + ch * n1 + roff, (size_t)rows * w * sizeof(float), c->s_h2d);
+                if (rc)
+                    break;
+            }
             HIPCHK(c, hipEventRecord(c->band_h2d[k], c->s_h2d));
             HIPCHK(c, hipStreamWaitEvent(c->s_kern, c->band_h2d[k], 0));
-            const float *const fp[3] = {c->d_frame + roff, c->d_frame + n1 + roff, c->d_frame + 2 * n1 + roff};
+            // (binary16 planes: the same element offsets behind a pointer to halves)
+            const float *const fp[3] = {use16 ? reinterpret_cast<const float *>(d16 + roff) : c->d_frame + roff,
+                                        use16 ? reinterpret_cast<const float *>(d16 + n1 + roff) : c->d_frame + n1 + roff,
+                                        use16 ? reinterpret_cast<const float *>(d16 + 2 * n1 + roff) : c->d_frame + 2 * n1 + roff};
             unsigned char *bp[3];
             for (int p = 0; p < 3; p++)
                 bp[p] = dp[p] + (size_t)((p && sub) ? r0 / 2 : r0) * stride[p];
             c->stream = c->s_kern;
-            rc = encode_frames_device_impl(c, fp, nfl, 1, w, rows, sc, profile, bp, stride, pfs, c->d_band_stats + 3 * k, cs_eff);
+            rc = encode_frames_device_impl(c, fp, nfl, 1, w, rows, sc, profile, bp, stride, pfs, c->d_band_stats + 3 * k, cs_eff, false, use16);
             c->stream = saved;
             if (rc)
                 break;
@@ -638,10 +782,20 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
             st[2] = fmaxf(st[2], bs[3 * k + 2]);
         }
     } else {
-        if ((rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
+        uint16_t *const d16 = reinterpret_cast<uint16_t *>(c->d_frame);
+        if (use16) {
+            bool exact = true;
+            if ((rc = xfer_h2d_f16(c, d16, rgb, nfl, c->stream, &exact)))
+                return rc;
+            if (!exact)
+                use16 = frame16 = false;   // (nothing has been launched on the halves: the floats simply follow on the same stream)
+        }
+        if (!use16 && (rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))
             return rc;
-        const float *const fp[3] = {c->d_frame, c->d_frame + n1, c->d_frame + 2 * n1};
-        if ((rc = encode_frames_device_impl(c, fp, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff)))
+        const float *const fp[3] = {use16 ? reinterpret_cast<const float *>(d16) : c->d_frame,
+                                    use16 ? reinterpret_cast<const float *>(d16 + n1) : c->d_frame + n1,
+                                    use16 ? reinterpret_cast<const float *>(d16 + 2 * n1) : c->d_frame + 2 * n1};
+        if ((rc = encode_frames_device_impl(c, fp, nfl, 1, w, h, sc, profile, dp, stride, pfs, c->d_stats, cs_eff, false, use16)))
             return rc;
         for (int p = 0; p < 3; p++)
             if ((rc = xfer_d2h_2d(c, planes[p], stride[p], dp[p], stride[p], L.row_bytes[p], L.rows[p], c->stream)))
@@ -658,11 +812,16 @@ static int encode_frame_host_impl(lumahip_ctx *c, const float *rgb, unsigned w, 
         return rc;
     if (transformed_out)
         HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (tried16)
+        in16_result(c, frame16);
     if (mean_lum) {
         *mean_lum = st[0] / (float)((int)w * (int)h);  // avg /= (w*h), src/luma_encoder.cpp:314
-        if (mean_needs_reference_sum(*mean_lum, st[1], w, h))  // d_frame holds the caller's frame, or already its transformed version
+        if (mean_needs_reference_sum(*mean_lum, st[1], w, h)) {  // d_frame holds the caller's frame (as floats or as halves), or already its transformed version
+            if (mixed && (rc = xfer_h2d(c, c->d_frame, rgb, nfl * sizeof(float), c->stream)))   // part halves, part floats: once more, whole
+                return rc;
             return transformed_out ? seq_mean(c, c->d_frame, w, h, mean_lum)
-                                   : mean_luminance_reference_impl(c, c->d_frame, w, h, sc, cs_eff, mean_lum);
+                                   : mean_luminance_reference_impl(c, c->d_frame, w, h, sc, cs_eff, mean_lum, frame16);
+        }
     }
     return LUMAHIP_OK;
 }
@@ -877,12 +1036,23 @@ extern "C" int lumahip_encode_frames_host(lumahip_ctx *c, const float *const *rg
             (void)hipStreamWaitEvent(c->s_h2d, sl.kern, 0);
             (void)hipStreamWaitEvent(c->s_kern, sl.d2h, 0);
         }
-        if ((rc = xfer_h2d(c, sl.d_frame, rgb[i], nfl * sizeof(float), c->s_h2d)))
+        // half upload (xfer_h2d_f16) where the frame holds halves; a frame that does not goes up as floats behind whatever part
+        // of it went up as halves (same stream, same slot, nothing launched on it yet)
+        bool f16 = in16_try(c, w, false);
+        if (f16) {
+            bool exact = true;
+            if ((rc = xfer_h2d_f16(c, sl.d_frame, rgb[i], nfl, c->s_h2d, &exact)))
+                break;
+            in16_result(c, exact);
+            f16 = exact;
+        }
+        if (!f16 && (rc = xfer_h2d(c, sl.d_frame, rgb[i], nfl * sizeof(float), c->s_h2d)))
             break;
         (void)hipEventRecord(sl.h2d, c->s_h2d);
         (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
         c->stream = c->s_kern;
-        rc = encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+        rc = f16 ? encode_packed16(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats)
+                 : encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
         c->stream = saved;
         if (rc)
             break;
@@ -957,14 +1127,26 @@ extern "C" int lumahip_encode_stream_push(lumahip_ctx *c, const float *rgb, unsi
     }
     c->up_ramp = 0;
     DnGuard dn_guard{c, false, seq + 1};   // until the frame counts as pushed, a failure drops the download chunks queued for it
-    const bool pinned_in = host_range_is_pinned(rgb, nfl * sizeof(float));
-    if ((rc = xfer_h2d(c, sl.d_frame, rgb, nfl * sizeof(float), c->s_h2d)))
+    bool pinned_in = host_range_is_pinned(rgb, nfl * sizeof(float));
+    bool f16 = in16_try(c, w, false);
+    if (f16) {   // half upload: the CPU converts out of the caller's memory (pinned or not), so it is free again when this returns
+        bool exact = true;
+        if ((rc = xfer_h2d_f16(c, sl.d_frame, rgb, nfl, c->s_h2d, &exact)))
+            return rc;
+        in16_result(c, exact);
+        f16 = exact;
+    }
+    if (f16)
+        pinned_in = false;
+    else if ((rc = xfer_h2d(c, sl.d_frame, rgb, nfl * sizeof(float), c->s_h2d)))
         return rc;
+    c->slot_in16[seq % 3] = f16;
     (void)hipEventRecord(sl.h2d, c->s_h2d);
     (void)hipStreamWaitEvent(c->s_kern, sl.h2d, 0);
     hipStream_t saved = c->stream;
     c->stream = c->s_kern;
-    rc = encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
+    rc = f16 ? encode_packed16(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats)
+             : encode_packed(c, sl.d_frame, nfl, 1, w, h, sc, profile, dp, stride, pfs, sl.d_stats);
     c->stream = saved;
     if (rc)
         return rc;
@@ -1013,7 +1195,7 @@ extern "C" int lumahip_encode_stream_pop(lumahip_ctx *c, float *mean_lum)
         const float *stp = c->h_es_stats + 3 * (seq % 3);
         *mean_lum = stp[0] / (float)((int)c->es_w * (int)c->es_h);
         if (mean_needs_reference_sum(*mean_lum, stp[1], c->es_w, c->es_h))   // the slot still holds the frame as it was uploaded
-            return mean_luminance_reference_impl(c, sl.d_frame, c->es_w, c->es_h, c->es_sc, c->q.cs, mean_lum);
+            return mean_luminance_reference_impl(c, sl.d_frame, c->es_w, c->es_h, c->es_sc, c->q.cs, mean_lum, c->slot_in16[seq % 3]);
     }
     return LUMAHIP_OK;
 }

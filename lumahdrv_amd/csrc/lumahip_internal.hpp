@@ -149,7 +149,14 @@ struct lumahip_ctx {
     bool numa_resolved = false;
     int numa_node = -1;        // -1: not a NUMA box / unknown / switched off
     std::vector<int> numa_cpus;
-    int copy_threads = 3;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only)
+    // Half upload of the host encode entry points (lumahip_host.hip xfer_h2d_f16): host frames that hold binary16 values cross
+    // PCIe as halves.  lumahip_tune("half_upload", v): 0 never, 1 (default) while the frames do hold halves, 2 always try.
+    int in16_mode = 1;
+    int in16_backoff = 0, in16_backoff_len = 0;
+    unsigned long in16_frames = 0, in16_fallbacks = 0;   // frames (or row bands) uploaded as halves / found to hold other values
+    bool slot_in16[3] = {false, false, false};           // stream push / pop: what the slot's device frame holds
+    int copy_threads = 5;      // lumahip_tune("copy_threads"): worker threads of the staging copies (0 = caller only); 3 until the half
+                               // upload, whose conversion is worth two more (batched half-valued 4K frames 4.9 -> 5.6 Gpixel/s; floats: no change)
     int copy_spin = 2000;      // lumahip_tune("copy_spin"): polls of an idle worker before it sleeps
 
     int block_threads = 256;
@@ -233,7 +240,10 @@ int check_layout(lumahip_ctx *c, unsigned w, unsigned h, int profile, unsigned n
 // rgb[c]: base of colour plane c; plane c of frame f at rgb[c] + f*frame_stride floats
 int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t frame_stride, unsigned nframes,
                               unsigned w, unsigned h, float sc, int profile, unsigned char *const planes[3],
-                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes = false);
+                              const int stride[3], const size_t pfs[3], float *stats, int cs_eff, bool lanes = false, bool in16 = false);
+// in16: rgb[] point at binary16 planes (the half upload of the host entry points, lumahip_host.hip); same element offsets and
+// strides; LUMAHIP_ERR_UNSUPPORTED unless encode_supports_in16() (records in LDS, rows of a multiple of 4 pixels)
+bool encode_supports_in16(lumahip_ctx *c, unsigned w);
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                 unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
                 const DisplayParams &dp, int cs_eff, bool lanes = false);
@@ -245,7 +255,7 @@ int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsi
 // ---- lumahip_misc.hip
 int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned h, float *mean_host);
 int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc, int cs_eff,
-                                  float *mean_host);
+                                  float *mean_host, bool in16 = false);   // in16: the frame at rgb_dev holds binary16 values
 
 // ---- lumahip_host.hip
 int xfer_h2d(lumahip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s);

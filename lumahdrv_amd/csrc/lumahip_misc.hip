@@ -185,7 +185,7 @@ int seq_mean(lumahip_ctx *c, const float *chan0_dev, unsigned w, unsigned h, flo
 
 // mean of transformed channel 0 of ONE device-resident (untransformed) frame, summed exactly as the reference does
 int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned w, unsigned h, float sc, int cs_eff,
-                                         float *mean_host)
+                                         float *mean_host, bool in16)
 {
     const size_t n = (size_t)w * h;
     int rc = ensure(c, (void **)&c->d_arr, &c->d_arr_cap, n * sizeof(float));
@@ -193,11 +193,11 @@ int mean_luminance_reference_impl(lumahip_ctx *c, const float *rgb_dev, unsigned
         return rc;
     void (*kern)(const float *, size_t, size_t, float, float, float *) = nullptr;
     switch (cs_eff) {
-    case CS_LUV: kern = k_channel0<CS_LUV>; break;
-    case CS_RGB: kern = k_channel0<CS_RGB>; break;
-    case CS_YCBCR: kern = k_channel0<CS_YCBCR>; break;
-    case CS_XYZ: kern = k_channel0<CS_XYZ>; break;
-    case CS_PACK: kern = k_channel0<CS_PACK>; break;
+    case CS_LUV: kern = in16 ? k_channel0<CS_LUV, true> : k_channel0<CS_LUV>; break;
+    case CS_RGB: kern = in16 ? k_channel0<CS_RGB, true> : k_channel0<CS_RGB>; break;
+    case CS_YCBCR: kern = in16 ? k_channel0<CS_YCBCR, true> : k_channel0<CS_YCBCR>; break;
+    case CS_XYZ: kern = in16 ? k_channel0<CS_XYZ, true> : k_channel0<CS_XYZ>; break;
+    case CS_PACK: kern = in16 ? k_channel0<CS_PACK, true> : k_channel0<CS_PACK>; break;
     }
     if (!kern)
         return fail(c, LUMAHIP_ERR_UNSUPPORTED, "Unrecognized color transformation (colour space %d)", cs_eff);

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -18,6 +19,23 @@
 #include "lumahip.h"
 
 namespace {
+// float -> nearest binary16 -> float (round to nearest even; the finite, non-tiny values of the test pattern): what a frame
+// looks like after the reference's EXR reader (Imf::Rgba, src/exr_interface.cpp:77-146)
+float to_half_and_back(float v)
+{
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    const uint32_t e = (b >> 23) & 0xff;
+    if (e < 113 || e > 142)   // below the normal halves / beyond 65504: not in the pattern; leave as it is
+        return v;
+    const uint32_t rem = b & 0x1fff, lsb = (b >> 13) & 1;
+    b &= ~0x1fffu;
+    if (rem > 0x1000 || (rem == 0x1000 && lsb))
+        b += 0x2000;
+    float r;
+    memcpy(&r, &b, 4);
+    return r;
+}
 struct NullSink : LumaPlaneSink {
     void open(const char *, unsigned int, unsigned int, int, float) {}
     void addAttachment(unsigned int, const void *, size_t, const char *) {}
@@ -70,6 +88,67 @@ int main(int argc, char **argv)
                 penc.encode(fr[i % 4].get());
             pipelined = n * px / (now() - tp) / 1e6;
             penc.finish();
+        }
+
+        // the same three loops on frames that hold binary16 values -- what ExrInterface::readFrame hands the encoder: such
+        // frames cross PCIe as halves (include/lumahip.h, "Half upload")
+        std::vector<std::unique_ptr<LumaFrame>> hfr;
+        for (int i = 0; i < 4; i++) {
+            hfr.emplace_back(new LumaFrame());
+            lumaTestFrame(*hfr.back(), w, h);
+            float *b = hfr.back()->buffer;
+            for (size_t j = 0; j < hfr.back()->pixelCount(); j++)   // (pixelCount() counts all three channels)
+                b[j] = to_half_and_back(b[j] * (1.0f + 0.01f * i));
+        }
+        double half_sync = 0.0, half_pipe = 0.0, half_batch = 0.0;
+        {
+            NullSink hsink;
+            LumaEncoder henc;
+            henc.setSink(&hsink);
+            henc.initialize("null", w, h);
+            henc.encode(hfr[0].get());
+            henc.encode(hfr[1].get());
+            double th = now();
+            for (int i = 0; i < n; i++)
+                henc.encode(hfr[i % 4].get());
+            half_sync = n * px / (now() - th) / 1e6;
+            NullSink psink;
+            LumaEncoder penc;
+            penc.setSink(&psink);
+            penc.setPipelined(true);
+            penc.initialize("null", w, h);
+            penc.encode(hfr[0].get());
+            penc.encode(hfr[1].get());
+            th = now();
+            for (int i = 0; i < n; i++)
+                penc.encode(hfr[i % 4].get());
+            half_pipe = n * px / (now() - th) / 1e6;
+            penc.finish();
+            // batched, pageable frames and planes
+            const LumaPlanes &him = henc.getRawFrame();
+            const int hst[3] = {him.stride[0], him.stride[1], him.stride[2]};
+            std::vector<std::vector<unsigned char>> hp(3 * 4);
+            for (int k = 0; k < 4; k++)
+                for (int p = 0; p < 3; p++)
+                    hp[3 * k + p].assign((size_t)him.planeHeight(p) * hst[p] + 4096, 0);
+            std::vector<const float *> hrgb(n);
+            std::vector<unsigned char *> hpl(3 * (size_t)n);
+            for (int i = 0; i < n; i++) {
+                hrgb[i] = hfr[i % 4]->buffer;
+                for (int p = 0; p < 3; p++)
+                    hpl[3 * (size_t)i + p] = hp[3 * (i % 4) + p].data();
+            }
+            lumahip_ctx *hctx = henc.getQuantizer()->context();
+            const LumaEncoderParams hprm = henc.getParams();
+            (void)lumahip_encode_frames_host(hctx, hrgb.data(), 4, w, h, hprm.preScaling, (int)hprm.profile, hpl.data(), hst, nullptr);
+            th = now();
+            if (lumahip_encode_frames_host(hctx, hrgb.data(), n, w, h, hprm.preScaling, (int)hprm.profile, hpl.data(), hst, nullptr) != LUMAHIP_OK)
+                throw LumaException(lumahip_last_error(hctx));
+            half_batch = n * px / (now() - th) / 1e6;
+            long hi[3] = {0, 0, 0};
+            (void)lumahip_half_upload_info(hctx, hi);
+            if (hi[0] == 0)
+                std::fprintf(stderr, "facade_hostfed: note: no frame went up as halves (no F16C on this host?)\n");
         }
 
         lumahip_ctx *ctx = enc.getQuantizer()->context();
@@ -193,11 +272,13 @@ int main(int argc, char **argv)
         }
         std::printf("{\"width\": %u, \"height\": %u, \"frames\": %d, \"unit\": \"Mpixels/s\", "
                     "\"LumaQuantizer_quantize_ns_per_call\": %.1f, \"LumaQuantizer_dequantize_ns_per_call\": %.1f, "
+                    "\"LumaEncoder_encode_pageable_half_valued_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_half_valued_frame\": %.1f, "
+                    "\"lumahip_encode_frames_host_pageable_half_valued\": %.1f, "
                     "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_frame\": %.1f, "
                     "\"LumaEncoder_encode_registered_frame\": %.1f, "
                     "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
                     "\"decode_frame_host_pageable\": %.1f, \"decode_stream_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
-                    w, h, n, q_ns, dq_ns, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
+                    w, h, n, q_ns, dq_ns, half_sync, half_pipe, half_batch, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;
