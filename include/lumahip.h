@@ -22,7 +22,8 @@
  *     independent.  "_host" entry points take host pointers and return when the results are in host
  *     memory; "_device" entry points take device pointers, enqueue on the context's stream and return
  *     immediately (lumahip_sync waits).
- *   - there is no CPU fallback: without a HIP device every entry point fails with LUMAHIP_ERR_HIP.
+ *   - there is no CPU fallback: without a HIP device every entry point that takes a context fails with LUMAHIP_ERR_HIP.  (The
+ *     functions marked "host-only" build tables or evaluate ONE value on the host, as the reference does, and take no context.)
  */
 #ifndef LUMAHIP_H
 #define LUMAHIP_H
