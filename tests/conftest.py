@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+# Order of the GPU suite (the driver runs `pytest -x -m gpu`; whatever stops the run must not stand in front of the
+# comparisons with the reference's results): golden-fixture and oracle parity -> BASELINE's full-size configurations ->
+# the other oracle comparisons -> exhaustive sweeps -> facade and tools -> bench contract, placement and TSan last.
+# Files not named here keep their alphabetical place between the sweeps and the facade.
+_GPU_ORDER = ["test_gpu_parity.py", "test_gpu_baseline_configs.py", "test_gpu_half_upload.py", "test_gpu_half_table.py",
+              "test_gpu_abi2.py", "test_gpu_exhaustive.py", None, "test_gpu_facade.py", "test_gpu_multi.py",
+              "test_gpu_placement.py", "test_gpu_tsan.py"]
+
+
+def gpu_suite_rank(filename):
+    return _GPU_ORDER.index(filename) if filename in _GPU_ORDER else _GPU_ORDER.index(None)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    # stable sort: the order inside a file is the order it is written in
+    items.sort(key=lambda it: gpu_suite_rank(os.path.basename(str(it.fspath))) if it.get_closest_marker("gpu") else -1)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle_py as o

@@ -101,6 +101,7 @@ int main(int argc, char **argv)
                 b[j] = to_half_and_back(b[j] * (1.0f + 0.01f * i));
         }
         double half_sync = 0.0, half_pipe = 0.0, half_batch = 0.0;
+        long hi[3] = {0, 0, 0};   // lumahip_half_upload_info of the batched half-valued call's context
         {
             NullSink hsink;
             LumaEncoder henc;
@@ -145,7 +146,6 @@ int main(int argc, char **argv)
             if (lumahip_encode_frames_host(hctx, hrgb.data(), n, w, h, hprm.preScaling, (int)hprm.profile, hpl.data(), hst, nullptr) != LUMAHIP_OK)
                 throw LumaException(lumahip_last_error(hctx));
             half_batch = n * px / (now() - th) / 1e6;
-            long hi[3] = {0, 0, 0};
             (void)lumahip_half_upload_info(hctx, hi);
             if (hi[0] == 0)
                 std::fprintf(stderr, "facade_hostfed: note: no frame went up as halves (no F16C on this host?)\n");
@@ -277,8 +277,10 @@ int main(int argc, char **argv)
                     "\"LumaEncoder_encode_pageable_frame\": %.1f, \"LumaEncoder_pipelined_encode_pageable_frame\": %.1f, "
                     "\"LumaEncoder_encode_registered_frame\": %.1f, "
                     "\"lumahip_encode_frames_host_pinned\": %.1f, \"lumahip_encode_frames_host_pageable\": %.1f, "
-                    "\"decode_frame_host_pageable\": %.1f, \"decode_stream_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f}\n",
-                    w, h, n, q_ns, dq_ns, half_sync, half_pipe, half_batch, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch);
+                    "\"decode_frame_host_pageable\": %.1f, \"decode_stream_pageable\": %.1f, \"lumahip_decode_frames_host_pageable\": %.1f, "
+                    "\"half_upload_info\": [%ld, %ld, %ld]}\n",
+                    w, h, n, q_ns, dq_ns, half_sync, half_pipe, half_batch, pageable, pipelined, registered, batch, batch_pageable, dec, dec_pipe, dec_batch,
+                    hi[0], hi[1], hi[2]);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_hostfed: %s\n", e.what());
         return 1;
