@@ -447,7 +447,9 @@ int lumahip_synth_frames_device(lumahip_ctx *ctx, float *dst_dev, size_t frame_s
 
 /* Timing helper for benchmarks: runs `iters` encode (dir=0) or decode (dir=1) launches of the same
  * arguments back to back on the context's stream between two hipEvents and returns the average
- * kernel-launch duration in milliseconds (events are recorded on the stream the kernels run on). */
+ * kernel-launch duration in milliseconds (events are recorded on the stream the kernels run on).
+ * dir = 2: an EMPTY kernel instead (the other arguments are ignored) -- the floor of this way of timing, ~6 us per launch on an
+ * MI355X, which every one-launch figure contains (profiles/r05_single_frame.txt). */
 int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb_dev, size_t frame_stride,
                           unsigned nframes, unsigned w, unsigned h, float sc, int profile,
                           unsigned char *const planes_dev[3], const int stride[3],
