@@ -31,7 +31,11 @@ traffic-only probe) and encode+decode round trip, the roofline of the encode ker
 `value_placement_off` (the same kernels on plainly allocated buffers), `other_workloads` (BASELINE configs[2] HDR10/YCbCr at
 4K and configs[3] LOG-12 at 7680x4320, each with its own roofline block and its decode rate; N = 1 only), `facade_hostfed`
 (LumaEncoder::encode(LumaFrame*) end to end on host frames -- PCIe-bound, never `value`) and the CPU reference timed on this
-host (`cpu_baseline`, N = 1 only).
+host (`cpu_baseline`, N = 1 only).  The YCbCr workload's `value` is measured on the synthetic stream, whose values are
+binary16-exact like every EXR frame of the reference (half-input table, HBM-bound); `float_inputs` and `mixed_inputs_1e-3` of the
+same block are the same stream with full-precision mantissas (what the reference's PFS pipe delivers; per-pixel powf, VALU-bound)
+and with 1e-3 of the pixels so, through the default kernel policy.  `--gpus N [--stream-frames F] --plan-only` prints every rank's
+shard, resident bytes and pool chunks without touching a GPU.
 """
 import argparse
 import json
@@ -84,11 +88,18 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-placement-off", action="store_true", help="skip the value_placement_off leg (the same kernels on plain allocations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-float-inputs", action="store_true",
+                    help="skip the float-input legs of the YCbCr workload (the same stream with full-precision mantissas / 1e-3 of them)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
     ap.add_argument("--placement", default="auto", choices=["auto", "off"],
                     help="auto: device memory is taken in 2 GiB chunks, their region groups found with traffic-only launches, and the "
                          "Y planes of the resident stream live in another group than its other buffers (lumahdrv_amd/placement.py); "
                          "off: plain allocations")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print what every rank of `--gpus N` would hold (shard, resident bytes, pool chunks) as one JSON line and exit; "
+                         "needs no GPU (then --hbm-free-gb says how much memory a rank has); exit code 1 when some rank does not fit")
+    ap.add_argument("--hbm-free-gb", type=float, default=0.0,
+                    help="--plan-only: free HBM per GPU in GB (default: what GPU 0 reports, or 280 of the MI355X's 288 GB without a GPU)")
     ap.add_argument("--profile-dir", default=os.path.join(ROOT, "profiles"),
                     help="where traffic_latest.json / valu_mix_latest.json (tools/summarize_profile.py) live")
     return ap.parse_args()
@@ -504,6 +515,52 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             r["roofline"] = enc_blk
             r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]
             r["decode_roofline"] = dec_blk
+    if cs == 2 and rank == 0 and world == 1 and not args.no_float_inputs:
+        # ---- the same stream when its values are NOT binary16 (the reference's PFS pipe hands the encoder arbitrary floats,
+        # src/pfs_interface.cpp:57-113): full-precision mantissas in every value, and in 1e-3 of the pixels, through the DEFAULT
+        # policy (lumahip_tune half_table 1; lumahip_core.hip half_policy).  Last leg of the workload: it rewrites the stream.
+        from lumahdrv_amd.placement import as_tensor
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(SEED)
+        mixf = mix.get("encode_float") if mix else None
+
+        def perturb(frac):
+            for b in range(nbatch):
+                v = as_tensor(ptrs(b)[0], B * n3 * 4, dev).view(torch.int32).view(B, 3, n1)
+                for f in range(B):                                  # per frame: small temporaries
+                    noise = torch.randint(1, 1 << 13, (3, n1), device=dev, dtype=torch.int32, generator=gen)
+                    if frac < 1.0:
+                        noise *= (torch.rand(n1, device=dev, generator=gen) < frac).to(torch.int32)[None]
+                    v[f] |= noise
+            torch.cuda.synchronize()
+
+        def float_leg(frac, what):
+            perturb(frac)
+            ctx.tune("half_table", 1)                               # the policy starts afresh, as for a new stream
+            i0 = ctx.half_table_info(sc)
+            tf = tm.run(enc)
+            tfo = tm.run(enc, lanes=0) if lanes else tf
+            i1 = ctx.half_table_info(sc)
+            ms_own = tfo["dev_ms_median"] / K
+            blk = {"value": round(rate(tf["wall_median"]), 1), "value_ordered": round(rate(tfo["wall_median"]), 1), "unit": "Mpixels/s",
+                   "inputs": what, "policy": "default (lumahip_tune half_table 1): table launches report float data, the per-pixel "
+                                               "kernel k_encode<CS_YCBCR,4:2:0,VW=4,LM=5> takes the launches of a back-off",
+                   "kernel_ms": round(tf["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(ms_own, 4),
+                   "table_launches": i1["table_launches"] - i0["table_launches"],
+                   "backoff_launches": i1["backoff_launches"] - i0["backoff_launches"],
+                   "hbm_frac": round(BYTES_PER_PIXEL * px_step / (ms_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            return blk, ms_own
+
+        fblk, fms = float_leg(1.0, "every value with a full-precision mantissa (13 random low bits): no binary16 value in the stream")
+        fblk["roofline"] = valu_block(mixf, fms, {k: enc_blk[k] for k in ("peak", "unit", "algorithmic_bytes_per_launch")})
+        fblk["roofline"]["hbm"]["achieved"] = round(BYTES_PER_PIXEL * px_step / (fms * 1e-3) / 1e9, 1)
+        fblk["roofline"]["hbm"]["frac"] = fblk["hbm_frac"]
+        r["float_inputs"] = fblk
+        # (the stream above is all floats already; a fresh synthetic stream for the 1e-3 point)
+        for b in range(nbatch):
+            ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
+        mblk, _ = float_leg(1e-3, "1e-3 of the pixels with full-precision mantissas in all three channels, the rest binary16 values")
+        r["mixed_inputs_1e-3"] = mblk
     ctx.close()
     if pool is not None:
         pool.give_back(src_c + out_c, y_c, uv_c, rgb_c)
@@ -547,12 +604,13 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
     free, _total = torch.cuda.mem_get_info(dev)
-    if (n3 * 4 + sum(psz)) * max(nfr, 1) > free * 0.9:
-        raise SystemExit("rank %d: shard of %d frames does not fit in HBM" % (rank, nfr))
-    steps = (nfr + B - 1) // B
+    plan = stream_shard_plan(F, rank, world, w, h, B, free, args.placement, profile)   # (what --plan-only prints)
+    if not plan["fits"]:
+        raise SystemExit("rank %d: shard of %d frames (%.1f GB) does not fit in HBM (%.1f GB free)"
+                         % (rank, nfr, plan["bytes_resident"] / 1e9, free / 1e9))
+    steps = plan["steps"]
     pool = None
-    shard_bytes = (n3 * 4 + sum(psz)) * nfr
-    if args.placement == "auto" and 8e9 <= shard_bytes <= free * 0.6:      # (a few GB: not worth probing 280 GB for)
+    if plan["pool"] is not None:
         pool = make_pool(L, args, dev, local_rank, w, h, B, nbatches=steps, with_output=False)
     if pool is not None:
         # step k's frames in chunk k of the pool's float chunks; Y and U / V planes in their own chunks (placement.py)
@@ -763,25 +821,91 @@ def cpu_baseline(args, cfg, w, h):
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
 
+def geometry(w, h, profile=2):
+    """(floats per frame, bytes of the Y / U / V planes of one frame) -- the plane layout of vpx_img_alloc(fmt(profile), w, h, 32)"""
+    from lumahdrv_amd import capi
+    _, hs, st, _ = capi.plane_geometry(w, h, profile)
+    return 3 * w * h, [hs[p] * st[p] for p in range(3)]
+
+
+def pool_request(w, h, B, decode_layout="auto", nbatches=None, with_output=True):
+    """what the resident stream of `nbatches` batches (default: configs[1]'s 500 frames or 50 GB of input, whichever is smaller)
+    asks of the chunk pool: chunks for float frames / Y planes / U+V planes / per region group for striped decode output.
+    None when a batch does not fit a chunk (the 2 GiB chunks hold a 20-frame 4K batch; larger batches use plain allocations)."""
+    from lumahdrv_amd.placement import CHUNK_BYTES, slots
+    n3, psz = geometry(w, h)
+    n1 = n3 // 3
+    ypc, _ = slots(CHUNK_BYTES, B * psz[0])
+    uvpc, _ = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+    spc, _ = slots(CHUNK_BYTES, B * n1 * 4)
+    if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
+        return None
+    nb = nbatches if nbatches else min(500 // B, max(1, int(50e9 // (B * n3 * 4))))
+    stripe = with_output and decode_layout == "auto" and spc >= 1
+    return {"batches": nb, "n_float": nb * (2 if (with_output and not stripe) else 1) + (PACKED_RING if stripe else 0),   # + the packed-layout decode leg
+            "n_y": -(-nb // ypc), "n_uv": -(-nb // uvpc), "n_striped": (-(-nb // spc) + PACKED_RING // 3 if stripe else 0),
+            "chunk_bytes": CHUNK_BYTES, "striped_output": bool(stripe)}
+
+
+def stream_shard_plan(F, rank, world, w, h, B, free, placement="auto", profile=2):
+    """--stream-frames mode (BASELINE configs[4]): what `rank` holds of the ONE F-frame stream -- its block, the bytes resident in
+    its HBM, whether they fit, and whether the shard is carved from the chunk pool (run_stream takes every decision from here)"""
+    from lumahdrv_amd.sharding import shard_range
+    n3, psz = geometry(w, h, profile)
+    mine = shard_range(F, rank, world)
+    nfr = len(mine)
+    per_frame = n3 * 4 + sum(psz)
+    resident = per_frame * max(nfr, 1)
+    steps = (nfr + B - 1) // B
+    use_pool = placement == "auto" and 8e9 <= per_frame * nfr <= free * 0.6      # (a few GB: not worth probing 280 GB for)
+    req = pool_request(w, h, B, nbatches=steps, with_output=False) if use_pool and steps else None
+    return {"rank": rank, "first_frame": mine.start, "frames": nfr, "steps": steps, "bytes_resident": resident,
+            "input_bytes": n3 * 4 * nfr, "plane_bytes": sum(psz) * nfr, "free_bytes": int(free), "fits": resident <= free * 0.9,
+            "pool": req, "placement": "chunk pool" if req else "plain allocations"}
+
+
+def plan_only(args):
+    """`bench.py --gpus N --plan-only`: the per-rank plan of the run the same command line would make, without touching a GPU"""
+    if args.hbm_free_gb > 0:
+        free = args.hbm_free_gb * 1e9
+    elif torch.cuda.is_available():
+        free = float(torch.cuda.mem_get_info(0)[0])
+    else:
+        free = 280e9
+    w, h, B, N = args.width, args.height, args.frames_per_step, args.gpus
+    ranks = []
+    if args.stream_frames > 0:
+        ranks = [stream_shard_plan(args.stream_frames, r, N, w, h, B, free, args.placement) for r in range(N)]
+        mode = "ONE %d-frame stream block-sharded over %d rank(s) (strong scaling)" % (args.stream_frames, N)
+    else:
+        n3, psz = geometry(w, h)
+        req = pool_request(w, h, B, args.decode_layout) if args.placement == "auto" else None
+        frames = (req["batches"] * B) if req else min(500, max(B, int(50e9 // (n3 * 4)) // B * B))
+        resident = frames * (2 * n3 * 4 + sum(psz)) + ((PACKED_RING * B * n3 * 4) if req and req["striped_output"] else 0)
+        pool_bytes = (req["n_float"] + req["n_y"] + req["n_uv"] + 3 * req["n_striped"]) * req["chunk_bytes"] if req else 0
+        for r in range(N):
+            ranks.append({"rank": r, "first_frame": r * frames, "frames": frames, "steps_per_pass": frames // B,
+                          "bytes_resident": resident, "pool_bytes": pool_bytes, "free_bytes": int(free),
+                          "fits": max(resident, pool_bytes) <= free * 0.9, "pool": req,
+                          "placement": "chunk pool" if req else "plain allocations"})
+        mode = "every rank its own %d-frame stream (weak scaling)" % frames
+    ok = all(r["fits"] for r in ranks)
+    print(json.dumps({"plan_only": True, "n_gpus": N, "mode": mode, "width": w, "height": h, "frames_per_step": B,
+                      "collective": "one broadcast of the table (2^bits floats) + an 8-value parameter block from rank 0; none on the data path",
+                      "fits": ok, "ranks": ranks}))
+    return 0 if ok else 1
+
+
 def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True):
     """--placement auto: the chunk pool (C ABI lumahip_pool_*) the resident streams are carved from (None: plain allocations)"""
     if args.placement != "auto":
         return None
     try:
-        from lumahdrv_amd.placement import CHUNK_BYTES, HbmChunkPool, slots
-        n1 = w * h
-        n3 = 3 * n1
-        _, hs, st, _ = L.plane_geometry(w, h, 2)
-        psz = [hs[p] * st[p] for p in range(3)]
-        ypc, _ = slots(CHUNK_BYTES, B * psz[0])
-        uvpc, _ = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
-        spc, _ = slots(CHUNK_BYTES, B * n1 * 4)
-        if B * n3 * 4 > CHUNK_BYTES or ypc < 1 or uvpc < 1:
+        from lumahdrv_amd.placement import HbmChunkPool
+        req = pool_request(w, h, B, args.decode_layout, nbatches, with_output)
+        if req is None:
             return None
-        nb = nbatches if nbatches else min(500 // B, max(1, int(50e9 // (B * n3 * 4))))   # default: the 500-frame stream (4K), input + decoded output
-        stripe = with_output and args.decode_layout == "auto" and spc >= 1
-        n_float = nb * (2 if (with_output and not stripe) else 1) + (PACKED_RING if stripe else 0)   # + the packed-layout decode leg
-        n_y, n_uv, n_striped = -(-nb // ypc), -(-nb // uvpc), (-(-nb // spc) + PACKED_RING // 3 if stripe else 0)
+        n_float, n_y, n_uv, n_striped = req["n_float"], req["n_y"], req["n_uv"], req["n_striped"]
         ctx = L.Context(local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
@@ -826,6 +950,8 @@ def facade_hostfed(w, h, runs=3):
 
 def main():
     args = parse()
+    if args.plan_only:
+        raise SystemExit(plan_only(args))
     multi_driver = args.stream_frames > 0 and args.driver == "multi"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not multi_driver:
         respawn(args)
@@ -903,6 +1029,9 @@ def main():
         if rank == 0:
             res["roofline"] = r["roofline"]
             res["decode_roofline"] = r["decode_roofline"]
+            for k in ("float_inputs", "mixed_inputs_1e-3"):     # (--workload pq10_ycbcr: the legs other_workloads.pq10_ycbcr_4k carries by default)
+                if k in r:
+                    res[k] = r[k]
         if pool is not None and args.workload == "pq11_luv" and not args.no_placement_off:
             # the same kernels on plainly allocated buffers (a 200-frame resident stream, 20 GB >> the 256 MB MALL):
             # what a caller that does not place its buffers gets

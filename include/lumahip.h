@@ -121,10 +121,12 @@ int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, fl
  * maxLum) seen, at most four), info[3] = table entries, info[4] = launches that took the half-input kernels so far, info[5] =
  * eligible launches that ran the per-pixel kernels instead because the stream did not look like binary16 data.
  * lumahip_tune("half_table", v): 0 = never use the table; 1 (default) = use it while the stream looks like binary16 data -- a
- * launch most of whose pixels are full-precision floats costs 1.4 x the per-pixel kernels' time on the table kernels, so the
- * kernels report such launches (one word of pinned host memory, no synchronisation) and the following 16 eligible launches run
- * per pixel before one launch tries the table again, the pause doubling up to 1024 launches while the reports continue;
- * 2 = always use it.  None of this changes a result. */
+ * launch most of whose pixels are full-precision floats costs 1.4 x the per-pixel kernels' time on the table kernels, so every
+ * table launch reports whether it was one (its own word of pinned host memory, read after the launch's completion event when
+ * the fourth eligible launch after it is issued: the choice of kernel is a function of the stream's data, never of timing);
+ * a report sends the following 16 eligible launches to the per-pixel kernels, then ONE launch tries the table again, and the
+ * pause doubles (up to 1024 launches) for every probe that reports again; a clean probe returns to the table.
+ * 2 = always use it.  lumahip_set_quantizer and this key start the policy afresh.  None of this changes a result. */
 int lumahip_ycbcr_half_table_host(float sc, float maxLum, float *out, size_t cap);
 int lumahip_half_table_info(lumahip_ctx *ctx, float sc, int info[6]);
 

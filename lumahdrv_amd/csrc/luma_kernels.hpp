@@ -51,11 +51,11 @@ struct EncArgs {
     int aligned;          // 1: vector stores allowed
     float *stats;         // nullable: per frame STATS_SLOTS partial {sum,min,max} triples (k_fold_stats folds them)
     const float *half;    // LM == 6 only: the half-input table of this (sc, Lmax), HALF_TABLE_LEN floats padded to 16 B (luma_device.hpp half_lookup)
-    // LM == 6 only, nullable: a word in host-visible memory that a workgroup overwrites with half_seq when every unit of every
+    // LM == 6 only, nullable: THIS launch's word in host-visible memory, which a workgroup sets to 1 when every unit of every
     // one of its waves held inputs that are not halves -- the stream is not binary16 data and the host stops picking this
-    // kernel for a while (lumahip_core.hip half_policy).  Feedback only: nothing a launch computes depends on it.
+    // kernel for a while (lumahip_core.hip half_policy reads the word after the launch's completion event).  Feedback only:
+    // nothing a launch computes depends on it.
     uint32_t *half_flag;
-    uint32_t half_seq;
 };
 
 struct DecArgs {
@@ -604,7 +604,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         if (valid)
             general = enc_transform<CS, VW, LM == 5 || LM == 6, HALF>(u, a, k, c0, c1, c2, st, s_half);
         if constexpr (HALF) {
-            n_units++;
+            // a tile that overhangs the frame may leave this wave without a single pixel: such a unit is no evidence either way
+            n_units += __builtin_amdgcn_ballot_w64(valid) != 0;
             n_general += __builtin_amdgcn_ballot_w64(general) != 0;
         }
         if (valid) {
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
             }
             __syncthreads();
             if (threadIdx.x == 0 && s_votes[0] > 0 && s_votes[0] == s_votes[1])
-                __hip_atomic_store(a.half_flag, a.half_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.half_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -89,7 +89,11 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipFree(c->d_ytab);
     for (auto &t : c->half_tabs)
         (void)hipFree(t.d);
-    if (c->h_half_flag) (void)hipHostFree(c->h_half_flag);
+    if (c->h_half_flag) {
+        for (auto &e : c->half_ev)
+            if (e) (void)hipEventDestroy(e);
+        (void)hipHostFree(c->h_half_flag);
+    }
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
@@ -282,7 +286,7 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         if (v < 0 || v > 2)
             return fail(c, LUMAHIP_ERR_ARG, "half_table must be 0 (off), 1 (while the stream is binary16 data) or 2 (always)");
         c->half_mode = (int)v;
-        c->half_backoff = c->half_backoff_len = 0;
+        half_policy_reset(c);
     } else if (k == "host_bands") {
         if (v < 1 || v > lumahip_ctx::MAX_BANDS)
             return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
@@ -502,6 +506,7 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    half_policy_reset(c);   // a new stream: the half-input policy starts afresh
     c->have_quant = false;
     c->h_lut.assign(lut, lut + n);
     c->q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);     // src/luma_quantizer.cpp:183
@@ -762,35 +767,112 @@ extern "C" int lumahip_numa_pin_current_thread(lumahip_ctx *c)
 
 // Which kernel an eligible launch takes (half_mode 1).  The half-input kernel evaluates units that hold anything but binary16
 // values with the general functions on top of its table reads -- 1.4 x the per-pixel kernels' time when EVERY pixel does that
-// (profiles/r04_half_miss_rate.txt), so a stream of full-precision floats (a PFS pipe rather than an EXR file) should not stay
-// on it.  The kernels report such launches through one word of pinned host memory (EncArgs::half_flag: plain stores, nobody
-// waits for them); a report sends the next 16 eligible launches to the per-pixel kernels, then one launch probes again, and
-// every further report in a row doubles the pause (up to 1024 launches: one probe in a thousand costs 0.04 %).  The word is
-// read when the next launch is issued, so the switch lags by however many launches the caller keeps in flight.
-bool half_policy(lumahip_ctx *c)
+// (profiles/r04_half_miss_rate.txt), so a stream of full-precision floats (a PFS pipe rather than an EXR file) must not stay
+// on it.  A table launch whose workgroups all found nothing but non-half data in every unit writes 1 into ITS feedback word
+// (EncArgs::half_flag, a ring of HALF_RING words of pinned host memory); an event is recorded right behind it.  The word of
+// table launch j is read when the eligible launch HALF_LAG after it is issued, once j's event has completed (normally long
+// ago; at most HALF_LAG - 1 launches stay queued behind it, so the device does not run dry).  The policy is a function of
+// those words in that order, i.e. of the data alone -- the same stream takes the same kernels on every run:
+//   ON_TABLE    table launches; a report -> BACKOFF for 16 launches (reports of the other launches in flight are dropped);
+//   BACKOFF     per-pixel launches; when the count runs out, ONE table launch probes -> PROBE_WAIT;
+//   PROBE_WAIT  per-pixel launches until the probe's word is read (HALF_LAG launches later): a report -> BACKOFF with the pause
+//               doubled (up to 1024: one probe in a thousand launches costs 0.04 %), none -> ON_TABLE and the pause forgotten.
+void half_policy_reset(lumahip_ctx *c)
 {
+    // reports of launches still in flight belong to the stream that ends here: wait for them, clear their words
+    for (const auto &p : c->half_pending) {
+        (void)hipEventSynchronize(c->half_ev[p.slot]);
+        __atomic_store_n(&c->h_half_flag[p.slot], 0u, __ATOMIC_RELAXED);
+    }
+    c->half_pending.clear();
+    c->half_state = lumahip_ctx::HALF_ON_TABLE;
+    c->half_backoff = c->half_backoff_len = 0;
+}
+
+static void half_report(lumahip_ctx *c, const lumahip_ctx::HalfPending &p, bool reported)
+{
+    using X = lumahip_ctx;
+    if (c->half_state == X::HALF_ON_TABLE) {
+        if (reported) {
+            c->half_reports++;
+            c->half_backoff_len = 16;
+            c->half_backoff = c->half_backoff_len;
+            c->half_state = X::HALF_BACKOFF;
+        }
+    } else if (c->half_state == X::HALF_PROBE_WAIT && p.probe) {
+        if (reported) {
+            c->half_reports++;
+            c->half_backoff_len = std::min(2 * std::max(c->half_backoff_len, 8), 1024);
+            c->half_backoff = c->half_backoff_len;
+            c->half_state = X::HALF_BACKOFF;
+        } else {
+            c->half_backoff_len = 0;
+            c->half_state = X::HALF_ON_TABLE;
+        }
+    }
+    // (BACKOFF, or a stale non-probe launch: the launches that were in flight when the first report arrived say nothing new)
+}
+
+bool half_policy(lumahip_ctx *c, uint32_t **flag)
+{
+    using X = lumahip_ctx;
+    *flag = nullptr;
     if (c->half_mode != 1)
         return c->half_mode == 2;
     if (!c->h_half_flag) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_half_flag), 64, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_half_flag), X::HALF_RING * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
             c->h_half_flag = nullptr;
             (void)hipGetLastError();
             return true;   // no feedback channel: behave like mode 2
         }
-        *c->h_half_flag = 0;
+        for (int i = 0; i < X::HALF_RING; i++) {
+            c->h_half_flag[i] = 0;
+            if (hipEventCreateWithFlags(&c->half_ev[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int j = 0; j < i; j++)
+                    (void)hipEventDestroy(c->half_ev[j]);
+                (void)hipHostFree(c->h_half_flag);
+                c->h_half_flag = nullptr;
+                return true;
+            }
+        }
     }
-    const uint32_t seen = __atomic_load_n(c->h_half_flag, __ATOMIC_RELAXED);
-    if (seen != c->half_flag_seen) {   // a launch since the last look held mostly non-half data
-        c->half_flag_seen = seen;
-        c->half_backoff_len = c->half_backoff_len ? std::min(2 * c->half_backoff_len, 1024) : 16;
-        c->half_backoff = c->half_backoff_len;
+    const unsigned long e = c->half_elig++;
+    // the words that are due: table launches issued HALF_LAG or more eligible launches ago, oldest first
+    while (!c->half_pending.empty() && c->half_pending.front().issued_at + X::HALF_LAG <= e) {
+        const X::HalfPending p = c->half_pending.front();
+        c->half_pending.erase(c->half_pending.begin());
+        (void)hipEventSynchronize(c->half_ev[p.slot]);
+        const bool reported = __atomic_load_n(&c->h_half_flag[p.slot], __ATOMIC_RELAXED) != 0;
+        __atomic_store_n(&c->h_half_flag[p.slot], 0u, __ATOMIC_RELAXED);
+        half_report(c, p, reported);
     }
-    if (c->half_backoff > 0) {
-        c->half_backoff--;
+    bool probe = false;
+    if (c->half_state == X::HALF_BACKOFF) {
+        if (c->half_backoff > 0) {
+            c->half_backoff--;
+            c->half_backoff_launches++;
+            return false;
+        }
+        c->half_state = X::HALF_PROBE_WAIT;
+        probe = true;
+    } else if (c->half_state == X::HALF_PROBE_WAIT) {
         c->half_backoff_launches++;
         return false;
     }
+    const int slot = (int)(c->half_seq % X::HALF_RING);   // free: at most HALF_LAG - 1 < HALF_RING launches are pending here
+    c->half_pending.push_back({e, slot, probe});
+    *flag = &c->h_half_flag[slot];
     return true;
+}
+
+// right behind a table launch that was given a feedback word: the event that says its word is final
+int half_launched(lumahip_ctx *c, hipStream_t s)
+{
+    if (c->half_pending.empty())
+        return LUMAHIP_OK;
+    HIPCHK(c, hipEventRecord(c->half_ev[c->half_pending.back().slot], s));
+    return LUMAHIP_OK;
 }
 
 // dynamic LDS of the encode-side kernels (search tables) and of the decode-side kernels (the table itself)

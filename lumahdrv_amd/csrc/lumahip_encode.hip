@@ -147,10 +147,11 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     const bool ycode = !in16 && cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
     // ... and R', G', B' of binary16 inputs from the half-input table of this call's (sc, Lmax), when table + records fit the LDS
     const float *half = nullptr;
+    uint32_t *half_flag = nullptr;   // this launch's feedback word (half_policy)
     if (ycode && c->half_mode != 0 && lds_bytes(c, true, cs_eff, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
         if ((rc = half_table_for(c, sc, &half)))
             return rc;
-        if (half && !half_policy(c))
+        if (half && !half_policy(c, &half_flag))
             half = nullptr;
     }
     EncArgs a{};
@@ -158,8 +159,8 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     a.half = half;
     if (half) {
         c->half_launches++;
-        a.half_flag = c->half_mode == 1 ? c->h_half_flag : nullptr;
-        a.half_seq = ++c->half_seq;   // (never the initial 0 of the feedback word for 2^32 launches)
+        c->half_seq++;
+        a.half_flag = half_flag;
     }
     const size_t lds = lds_bytes(c, true, cs_eff, ycode, half != nullptr);
     const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
@@ -210,6 +211,8 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         hipLaunchKernelGGL(k_init_stats, dim3((np + 255) / 256), dim3(256), 0, s, c->d_stats_part, np);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
+    if (half_flag && (rc = half_launched(c, s)))
+        return rc;
     if (stats)
         hipLaunchKernelGGL(k_fold_stats, dim3((nframes + 63) / 64), dim3(64), 0, s, c->d_stats_part, stats, (int)nframes);
     HIPCHK(c, hipGetLastError());

@@ -69,11 +69,25 @@ struct lumahip_ctx {
     std::vector<HalfTab> half_tabs;
     unsigned long half_clock = 0;
     int half_mode = 1;            // lumahip_tune("half_table"): 0 = never, 1 = while the stream looks like binary16 data (half_policy), 2 = always
-    // feedback of the half-input kernels (EncArgs::half_flag): one word of pinned host memory the kernels write and nobody waits for
-    uint32_t *h_half_flag = nullptr;
-    uint32_t half_seq = 0, half_flag_seen = 0;
+    // Feedback of the half-input kernels (EncArgs::half_flag; lumahip_core.hip half_policy): every table launch has its OWN word
+    // in a ring of pinned host memory and an event recorded behind it; the host reads launch j's word when it issues the
+    // eligible launch HALF_LAG later, after that event has completed -- so which kernel a launch takes is a function of the
+    // stream's data and of nothing else (no timing).
+    static constexpr int HALF_LAG = 4, HALF_RING = 8;
+    uint32_t *h_half_flag = nullptr;                 // HALF_RING words
+    hipEvent_t half_ev[HALF_RING] = {};
+    struct HalfPending {
+        unsigned long issued_at;                     // index of the eligible launch this table launch was
+        int slot;
+        bool probe;                                  // the single table launch at the end of a back-off
+    };
+    std::vector<HalfPending> half_pending;           // oldest first; at most HALF_LAG entries
+    unsigned long half_elig = 0;                     // eligible launches so far (table or not)
+    uint32_t half_seq = 0;                           // table launches so far
+    enum { HALF_ON_TABLE = 0, HALF_BACKOFF = 1, HALF_PROBE_WAIT = 2 };
+    int half_state = HALF_ON_TABLE;
     int half_backoff = 0, half_backoff_len = 0;      // launches left on the per-pixel kernels; length of the current back-off
-    unsigned long half_launches = 0, half_backoff_launches = 0;
+    unsigned long half_launches = 0, half_backoff_launches = 0, half_reports = 0;
     bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
     std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer
     float *d_lut = nullptr;
@@ -225,8 +239,12 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int fe
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
 int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the device half-input table of (sc, the quantizer's Lmax), or nullptr: none
-bool half_policy(lumahip_ctx *c);
-void numa_resolve(lumahip_ctx *c);                                 // fills numa_node / numa_cpus once (cheap afterwards)                                  // this launch: the half-input kernel (true) or the per-pixel one
+// this eligible launch: the half-input kernel (true) or the per-pixel one.  On true, *flag is the launch's feedback word (nullptr:
+// none wanted) and the caller calls half_launched(c, stream) right behind the kernel launch.
+bool half_policy(lumahip_ctx *c, uint32_t **flag);
+int half_launched(lumahip_ctx *c, hipStream_t s);
+void half_policy_reset(lumahip_ctx *c);
+void numa_resolve(lumahip_ctx *c);                                 // fills numa_node / numa_cpus once (cheap afterwards)
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);
 hipStream_t launch_stream(lumahip_ctx *c, bool lanes);   // the context's stream, or -- for the entry points that take part in unordered sections -- the next lane of an open one

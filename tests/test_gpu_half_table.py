@@ -155,41 +155,91 @@ def test_pairs_without_a_table_and_the_table_cache(oracle_mod):
         assert np.array_equal(got[p], exp[p]), p
 
 
+def _half_policy_model(kinds, lag=4):
+    """lumahip_core.hip half_policy restated: kinds[i] = True when eligible launch i holds full-precision floats (a table launch on
+    it reports).  Returns, per launch, (table launches so far, back-off launches so far) AFTER it was issued."""
+    ON, BACKOFF, PROBE_WAIT = 0, 1, 2
+    state, left, length, pending, table, backoff, out = ON, 0, 0, [], 0, 0, []
+    for e, is_float in enumerate(kinds):
+        while pending and pending[0][0] + lag <= e:
+            _, reported, probe = pending.pop(0)
+            if state == ON and reported:
+                state, length = BACKOFF, 16
+                left = length
+            elif state == PROBE_WAIT and probe:
+                if reported:
+                    length = min(2 * max(length, 8), 1024)
+                    state, left = BACKOFF, length
+                else:
+                    state, length = ON, 0
+        probe = False
+        if state == BACKOFF and left > 0:
+            left -= 1
+            backoff += 1
+        elif state == PROBE_WAIT:
+            backoff += 1
+        else:
+            if state == BACKOFF:
+                state, probe = PROBE_WAIT, True
+            pending.append((e, is_float, probe))
+            table += 1
+        out.append((table, backoff))
+    return out
+
+
 def test_float_streams_back_off_to_the_per_pixel_kernels(oracle_mod):
-    """lumahip_tune half_table 1 (the default): a launch whose pixels are mostly full-precision floats reports itself, the next
-    16 eligible launches run the per-pixel kernels, then one launch probes the table again (pause doubling while the reports
-    continue); a stream of halves stays on the table.  Every launch equals the oracle whichever kernel ran."""
+    """lumahip_tune half_table 1 (the default): every table launch reports into its own word whether its pixels were mostly
+    full-precision floats; the host reads launch j's word when it issues eligible launch j + 4, after j's completion event.  A
+    report sends 16 launches to the per-pixel kernels, then ONE launch probes the table (pause doubling while the probes report
+    again, forgotten after a clean probe).  Which kernel a launch takes is therefore a function of the stream's data alone: the
+    launch counts must equal the model's after EVERY launch, with a host synchronisation after each launch and with none at
+    all.  Every launch equals the oracle whichever kernel ran."""
     import lumahdrv_amd as L
     o = oracle_mod
     cfg = (L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01)
-    q = L.LumaQuantizer()
-    q.setQuantizer(*cfg)
     orc = o.Oracle(*cfg)
-    c = q.ctx
     sc, w, h = 20.0, 512, 64
     rng = np.random.default_rng(11)
     fl = np.exp(rng.uniform(np.log(1e-3), np.log(1e4), size=(3, h, w))).astype(np.float32)
     hf = fl.astype(np.float16).astype(np.float32)
-    exp_fl, _, _ = orc.encode(fl.copy(), sc, 2)
-    exp_hf, _, _ = orc.encode(hf.copy(), sc, 2)
-
-    def run(frame, exp):
-        got, _ = _encode_device(c, L, frame, sc, 2)      # (synchronises: the report is visible to the next launch)
-        for p in range(3):
-            assert np.array_equal(got[p], exp[p])
+    exp = {True: orc.encode(fl.copy(), sc, 2)[0], False: orc.encode(hf.copy(), sc, 2)[0]}
+    # halves, a burst of floats (report + 16 per pixel + probe that reports again + 32 per pixel), halves again (clean probe,
+    # back on the table), one float launch in the middle of halves, a tail of halves
+    kinds = [False] * 2 + [True] * 30 + [False] * 60 + [True] + [False] * 40
+    model = _half_policy_model(kinds)
+    assert model[1] == (2, 0) and model[5] == (6, 0) and model[6] == (6, 1) and model[21] == (6, 16) and model[22] == (7, 16)
+    assert model[26] == (7, 20) and model[-1][0] > 40           # (what the docstring says, spelled out once)
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    sizes = [hs[p] * st[p] for p in range(3)]
+    for sync_each in (True, False):
+        q = L.LumaQuantizer()
+        q.setQuantizer(*cfg)
+        c = q.ctx
+        assert c.half_table_info(sc)["used"]
+        d_src = {k: c.malloc(fl.nbytes) for k in (True, False)}
+        c.h2d(d_src[True], fl)
+        c.h2d(d_src[False], hf)
+        d_pl = [[c.malloc(n) for n in sizes] for _ in kinds]            # every launch has its own planes
+        for pl in d_pl:
+            for p in range(3):
+                c.h2d(pl[p], np.zeros(sizes[p], dtype=np.uint8))
+        for e, k in enumerate(kinds):
+            c.encode_frames_device(d_src[k], 3 * w * h, 1, w, h, sc, 2, d_pl[e], st, sizes)
+            if sync_each:
+                c.sync()
+            i = c.half_table_info(sc)
+            assert (i["table_launches"], i["backoff_launches"]) == model[e], (sync_each, e)
+        c.sync()
+        for e, k in enumerate(kinds):
+            for p in range(3):
+                got = np.empty((hs[p], st[p]), dtype=np.uint8)
+                c.d2h(got, d_pl[e][p])
+                assert np.array_equal(got, exp[k][p]), (sync_each, e, p)
+        n_table, n_back = model[-1]
+        c.tune("half_table", 2)                                         # always: no reports, no pauses
+        c.encode_frames_device(d_src[True], 3 * w * h, 1, w, h, sc, 2, d_pl[0], st, sizes)
+        c.sync()
         i = c.half_table_info(sc)
-        return i["table_launches"], i["backoff_launches"]
-
-    assert c.half_table_info(sc)["used"]
-    assert run(hf, exp_hf) == (1, 0) and run(hf, exp_hf) == (2, 0)     # halves: on the table
-    assert run(fl, exp_fl) == (3, 0)                                   # floats: this launch reports ...
-    for k in range(16):
-        assert run(fl, exp_fl) == (3, k + 1)                           # ... 16 launches per pixel
-    assert run(fl, exp_fl) == (4, 16)                                  # probe: still floats
-    for k in range(32):
-        assert run(hf, exp_hf) == (4, 17 + k)                          # pause doubled to 32 (the stream has changed, nobody looked yet)
-    assert run(hf, exp_hf) == (5, 48)                                  # probe: halves again
-    for k in range(5):
-        assert run(hf, exp_hf) == (6 + k, 48)                          # and it stays on the table
-    c.tune("half_table", 2)
-    assert run(fl, exp_fl) == (11, 48) and run(fl, exp_fl) == (12, 48)  # always: no reports, no pauses
+        assert (i["table_launches"], i["backoff_launches"]) == (n_table + 1, n_back)
+        for b in list(d_src.values()) + [x for pl in d_pl for x in pl]:
+            c.free(b)

@@ -184,3 +184,13 @@ def test_bench_config3_encode_is_hbm_bound():
     dr = r["decode_roofline"]
     assert dr["bound"] == "valu" and 0 < dr["hbm"]["frac"] < 1
     assert dr["frac"] is None or dr["frac"] > 0               # (VALU roofline from the committed instruction mix, when it matches the sources)
+    # the other input class of this configuration: the same stream with full-precision mantissas (what the reference's PFS pipe
+    # delivers, src/pfs_interface.cpp:57-113) through the DEFAULT policy -- VALU-bound, and the launches of each kind are exactly
+    # what the policy's model says for a stream of that many float launches (a function of the data, not of timing)
+    from tests.test_gpu_half_table import _half_policy_model
+    fi = r["float_inputs"]
+    assert fi["value"] > 0 and fi["roofline"]["bound"] == "valu" and 0 < fi["hbm_frac"] < 1
+    n = fi["table_launches"] + fi["backoff_launches"]
+    assert n >= 8 and _half_policy_model([True] * n)[-1] == (fi["table_launches"], fi["backoff_launches"]), fi
+    mi = r["mixed_inputs_1e-3"]
+    assert mi["value"] > 0 and mi["backoff_launches"] == 0 and mi["table_launches"] >= 8, mi   # 1e-3 of the pixels: stays on the table

@@ -153,3 +153,142 @@ def test_bench_timer_loop_with_two_ranks(tmp_path):
     assert r[0]["ranks"] == pytest.approx(r[1]["ranks"]) and len(r[0]["ranks"]) == 2
     assert r[0]["ranks"][1] > r[0]["ranks"][0]                     # rank 1 slept longer
     assert r[0]["wall_median"] >= 0.999 * max(r[0]["ranks"]) - 1e-3
+
+
+# ---- world size 8: what the driver's 8-GPU node will run first (the gpurun boxes have one GPU) -----------------------------
+
+def _worker8(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lumahdrv_amd import capi
+    from lumahdrv_amd.sharding import ShardedStream, gather_in_stream_order, shard_range
+    from oracle import oracle_py as o
+    dev = torch.device("cpu")
+    # (1) 37 frames over 8 ranks (5 ranks with 5 frames, 3 with 4): the whole ShardedStream, oracle standing in for the GPU
+    cfg = lut = None
+    if rank == 0:
+        cfg = (capi.PTF_PQ, 11, capi.CS_LUV, 8, 1e4, 0.005, 1.0, 2)
+        lut = capi.build_lut(capi.PTF_PQ, 11, 1e4, 0.005)
+    st = ShardedStream(37, dev, cfg, lut)
+
+    def make_worker(cfg, lut):
+        orc = o.Oracle(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5])
+        orc.overwrite_mapping(lut)
+        return orc
+
+    def process(orc, f):
+        planes, _, _ = orc.encode(o.synth_frame(32, 16, frame=f), st.cfg[6], st.cfg[7])
+        return o.fnv1a64(np.concatenate([p.ravel() for p in planes]))
+
+    d37 = st.run(make_worker, process)
+    # (2) BASELINE configs[4]'s plan: 2000 frames, 250 per rank; (3) fewer frames than ranks (ranks 5..7 own nothing)
+    mine = shard_range(2000, rank, world)
+    d2000 = gather_in_stream_order([(f * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF for f in mine], 2000, dev)
+    d5 = gather_in_stream_order([1000 + f for f in shard_range(5, rank, world)], 5, dev)
+    np.save(os.path.join(out_dir, "r%d_37.npy" % rank), np.array(d37, dtype=np.int64))
+    np.save(os.path.join(out_dir, "r%d_2000.npy" % rank), np.array(d2000, dtype=np.int64))
+    np.save(os.path.join(out_dir, "r%d_5.npy" % rank), np.array(d5, dtype=np.int64))
+    np.save(os.path.join(out_dir, "r%d_own.npy" % rank), np.array([len(st.frames), len(mine)], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_streams_with_uneven_shards(tmp_path):
+    """world size 8 (gloo, CPU): 37 frames (shards of 5 and 4), 2000 frames (250 each, configs[4]) and 5 frames (three ranks
+    without a frame) come back in stream order on EVERY rank; the 37-frame stream's digests equal a single-process run"""
+    from oracle import oracle_py as o
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    orc = o.Oracle(o.PTF_PQ, 11, o.CS_LUV, 8, 1e4, 0.005)
+    e37 = []
+    for f in range(37):
+        planes, _, _ = orc.encode(o.synth_frame(32, 16, frame=f), 1.0, 2)
+        e37.append(o.fnv1a64(np.concatenate([p.ravel() for p in planes])) & 0x7FFFFFFFFFFFFFFF)
+    e2000 = [(f * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF for f in range(2000)]
+    for r in range(world):
+        assert np.load(tmp_path / ("r%d_37.npy" % r)).tolist() == e37
+        assert np.load(tmp_path / ("r%d_2000.npy" % r)).tolist() == e2000
+        assert np.load(tmp_path / ("r%d_5.npy" % r)).tolist() == [1000, 1001, 1002, 1003, 1004]
+        assert np.load(tmp_path / ("r%d_own.npy" % r)).tolist() == [5 if r < 5 else 4, 250]
+
+
+def _timer_worker8(rank, world, port, out_dir):
+    import json
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = _bench_module()
+    calls = []
+
+    def step(i):
+        calls.append(i)
+        time.sleep(0.006 if rank == 5 else 0.001)     # rank 5 is the slow one
+
+    tm = b.Timer(2, 1, True, torch.device("cpu"), 0.01, 20)
+    res = tm.run(step)
+    json.dump({"repeats": res["repeats"], "calls": calls, "wall_median": res["wall_median"], "ranks": res["rank_wall_medians"]},
+              open(os.path.join(out_dir, "timer%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timer_loop_with_eight_ranks(tmp_path):
+    """bench.py's Timer at world size 8: every rank runs the same regions (rank 0 decides), the region time is the slowest
+    rank's on every rank, and rank_wall_medians names it"""
+    import json
+    world = 8
+    mp.spawn(_timer_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / ("timer%d.json" % k))) for k in range(world)]
+    assert len({x["repeats"] for x in r}) == 1 and r[0]["repeats"] >= 1
+    n = 1 + 2 * r[0]["repeats"]
+    assert all(x["calls"] == list(range(n)) for x in r)
+    assert all(x["wall_median"] == pytest.approx(r[0]["wall_median"]) for x in r)
+    assert all(len(x["ranks"]) == 8 and x["ranks"] == pytest.approx(r[0]["ranks"]) for x in r)
+    assert int(np.argmax(r[0]["ranks"])) == 5
+    assert r[0]["wall_median"] >= 0.999 * max(r[0]["ranks"]) - 1e-3
+
+
+def _plan(argv):
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--plan-only", "--hbm-free-gb", "280"],
+                         capture_output=True, text=True, timeout=120)
+    return out.returncode, (json.loads(out.stdout.strip().splitlines()[-1]) if out.stdout.strip() else None)
+
+
+def test_bench_plan_only_for_eight_gpus():
+    """`bench.py --gpus 8 [--stream-frames 2000] --plan-only` needs no GPU and prints what every rank would hold; the numbers
+    are the ones run_workload / run_stream / make_pool size their buffers with (same functions)"""
+    from lumahdrv_amd.sharding import shard_range
+    rc, d = _plan(["--gpus", "8"])
+    assert rc == 0 and d["fits"] and d["n_gpus"] == 8 and len(d["ranks"]) == 8
+    n3 = 3 * 3840 * 2160
+    for r, p in enumerate(d["ranks"]):
+        assert p["rank"] == r and p["frames"] == 500 and p["first_frame"] == 500 * r and p["steps_per_pass"] == 25
+        # input + decoded output + planes (Y 2 B, U and V 0.5 B per pixel) + the packed-layout decode ring
+        assert p["bytes_resident"] == 500 * (2 * n3 * 4 + 3 * 3840 * 2160) + 6 * 20 * n3 * 4
+        assert p["pool"]["n_float"] == 25 + 6 and p["pool"]["striped_output"] and p["placement"] == "chunk pool"
+        assert p["pool_bytes"] < 0.9 * p["free_bytes"]
+    rc, d = _plan(["--gpus", "8", "--stream-frames", "2000"])
+    assert rc == 0 and d["fits"]
+    for r, p in enumerate(d["ranks"]):
+        rg = shard_range(2000, r, 8)
+        assert (p["first_frame"], p["frames"], p["steps"]) == (rg.start, 250, 13)
+        assert p["bytes_resident"] == 250 * (n3 * 4 + 3 * 3840 * 2160) and p["placement"] == "chunk pool"
+        assert p["pool"]["n_float"] == 13                              # one chunk per 20-frame step
+    # N = 1 holds the whole stream (249 GB): fits, but leaves no room for the pool; 3000 frames do not fit and the exit code says so
+    rc, d = _plan(["--gpus", "1", "--stream-frames", "2000"])
+    assert rc == 0 and d["ranks"][0]["placement"] == "plain allocations" and d["ranks"][0]["bytes_resident"] == 2000 * (n3 * 4 + 3 * 3840 * 2160)
+    rc, d = _plan(["--gpus", "1", "--stream-frames", "3000"])
+    assert rc == 1 and not d["fits"]
+    # uneven: 37 frames over 8 ranks
+    rc, d = _plan(["--gpus", "8", "--stream-frames", "37"])
+    assert rc == 0 and [p["frames"] for p in d["ranks"]] == [5, 5, 5, 5, 5, 4, 4, 4]
+    assert all(p["placement"] == "plain allocations" for p in d["ranks"])

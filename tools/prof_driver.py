@@ -41,6 +41,24 @@ def main():
         for b in range(n):
             pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
             ctx.decode_frames_device(pl, st, psz, B, w, h, 2, sc, out.data_ptr() + b * B * n3 * 4, n3)
+    if cs == L.CS_YCBCR:
+        # the per-pixel encode kernel (k_encode<CS_YCBCR, ., ., LM = 5>: what a stream of full-precision floats runs after the
+        # half-input policy has backed off) on its own input class, for bench.py's float_inputs VALU roofline: a second stream
+        # whose values all carry random low mantissa bits, with the half-input table switched off
+        fsrc = src.clone()
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        v = fsrc.view(torch.int32).view(n * B * 3, w * h)
+        for i in range(v.shape[0]):
+            v[i] |= torch.randint(1, 1 << 13, (w * h,), device=dev, dtype=torch.int32, generator=g)
+        ctx.tune("half_table", 0)
+        for rep in range(2):
+            for b in range(n):
+                pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
+                ctx.encode_frames_device(fsrc.data_ptr() + b * B * n3 * 4, n3, B, w, h, sc, 2, pl, st, psz)
+        ctx.tune("half_table", 1)
+        torch.cuda.synchronize()
+        del fsrc
     # the traffic-only probes (same loads and stores, no arithmetic): known byte counts in the kernels' own access patterns,
     # i.e. the calibration of FETCH_SIZE / WRITE_SIZE the microarchitecture guide asks for (they overwrite planes / frames)
     for b in range(n):

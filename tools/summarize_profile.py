@@ -124,7 +124,13 @@ def main():
             continue
         for k, d in load(p).items():
             c.setdefault(k, {}).update(d)
-    enc = next(k for k in c if "k_encode<" in k)
+    encs = sorted(k for k in c if "k_encode<" in k)
+    # pq10_ycbcr: the half-input kernel (LM = 6: `<2, true, 4, 6, false>`) is the workload's encode kernel, the per-pixel one
+    # (LM = 5) is what prof_driver.py ran on its float stream
+    def lm(k):
+        return k.split("k_encode<")[1].split(">")[0].replace(" ", "").split(",")[3]
+    enc = next((k for k in encs if lm(k) == "6"), encs[0])
+    enc_float = next((k for k in encs if lm(k) == "5" and k != enc), None)
     dec = next(k for k in c if "k_decode<" in k)
     syn = next((k for k in c if "k_synth" in k), None)
     eprobe = next((k for k in c if "k_encode_traffic_probe" in k), None)
@@ -142,7 +148,10 @@ def main():
             cal[w_key] = alg[w_key] / (c[probe]["WRITE_SIZE"] * 1024)
             cal_src[r_key] = cal_src[w_key] = "measured on `%s` in the same run" % probe
     mixes, traffic = {}, {}
-    for name, k, r_key, w_key in (("encode", enc, "enc_r", "enc_w"), ("decode", dec, "dec_r", "dec_w")):
+    kernels = [("encode", enc, "enc_r", "enc_w"), ("decode", dec, "dec_r", "dec_w")]
+    if enc_float:
+        kernels.append(("encode_float", enc_float, "enc_r", "enc_w"))
+    for name, k, r_key, w_key in kernels:
         d = c[k]
         lines += ["## %s: `%s`" % (name, k), "", "| counter | per launch |", "|---|---|"]
         lines += ["| %s | %.4g |" % (cn, v) for cn, v in sorted(d.items())]
@@ -245,6 +254,7 @@ def main():
     if "encode" in mixes:
         update_json(os.path.join(dst, "valu_mix_latest.json"), wl,
                     dict(mixes["encode"], tag=tag, workload=wl, kernel_source_sha=sha, commit=commit, decode=mixes.get("decode"),
+                         encode_float=mixes.get("encode_float"),
                          note="PMC class counters x issue costs of tools/bench/valu_bench.hip (tools/summarize_profile.py)"))
     print("\n".join(lines[-24:]))
 
