@@ -353,6 +353,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             torch.cuda.empty_cache()
         return r, cfg
     td = tm.run(dec)                                       # (the planes every batch holds are the encode leg's)
+    rb_after_random = ctx.rb_table_info(sc) if cs == 2 else None
     r["decode_mpix_s"] = round(rate(td["wall_median"]), 1)
     r["decode_output_layout"] = ("R, G, B planes of a batch in three HBM region groups (lumahip_decode_frames_device_planar)"
                                  if striped else "packed LumaFrame layout")
@@ -551,6 +552,37 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                    "hbm_frac": round(BYTES_PER_PIXEL * px_step / (ms_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return blk, ms_own
 
+        if legs == "full":
+            # ---- decode of a PICTURE-like stream.  The legs above decode the planes of the synthetic stream, whose pixels are
+            # unrelated: there no wave finds its codes local, the red / blue tables are never read (six powf per pixel,
+            # and the launch-level policy soon picks the kernels without the test).  The same stream low-pass filtered in the log
+            # domain (32 x 32 box, bilinear up: neighbouring pixels, neighbouring codes -- what video looks like) takes the tables.
+            import torch.nn.functional as F
+            for b in range(nbatch):
+                v = as_tensor(ptrs(b)[0], B * n3 * 4, dev).view(torch.float32).view(B * 3, 1, h, w)
+                for i in range(B * 3):
+                    lo = F.avg_pool2d(torch.log(v[i:i + 1]), 32)
+                    v[i:i + 1] = torch.exp(F.interpolate(lo, size=(h, w), mode="bilinear", align_corners=False))
+                enc(b)
+            torch.cuda.synchronize()
+            ctx.tune("ycbcr_rb_tables", 1)                          # the policy starts afresh, as for a new stream
+            j0 = ctx.rb_table_info(sc)
+            tc = tm.run(dec)
+            tco = tm.run(dec, lanes=0) if lanes else tc
+            j1 = ctx.rb_table_info(sc)
+            cms = tco["dev_ms_median"] / K
+            r["decode_coherent"] = {
+                "value": round(rate(tc["wall_median"]), 1), "value_ordered": round(rate(tco["wall_median"]), 1), "unit": "Mpixels/s",
+                "inputs": "the planes of the same stream low-pass filtered in the log domain (32 x 32 box): a picture's statistics",
+                "kernel": "lh::k_decode<CS_YCBCR,4:2:0,VW=4,y table in LDS,red / blue tables in global memory>: a wave whose codes are "
+                          "local reads red and blue (two 4-byte gathers) and computes green (two powf); others compute all three",
+                "kernel_ms": round(tc["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(cms, 4),
+                "hbm_frac": round(BYTES_PER_PIXEL * px_step / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "rb_table_bytes": j1["bytes"], "table_launches": j1["table_launches"] - j0["table_launches"],
+                "backoff_launches": j1["backoff_launches"] - j0["backoff_launches"]}
+            r["decode_random_rb_policy"] = {k: rb_after_random[k] for k in ("table_launches", "backoff_launches")}
+            for b in range(nbatch):
+                ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
         fblk, fms = float_leg(1.0, "every value with a full-precision mantissa (13 random low bits): no binary16 value in the stream")
         fblk["roofline"] = valu_block(mixf, fms, {k: enc_blk[k] for k in ("peak", "unit", "algorithmic_bytes_per_launch")})
         fblk["roofline"]["hbm"]["achieved"] = round(BYTES_PER_PIXEL * px_step / (fms * 1e-3) / 1e9, 1)

@@ -130,6 +130,22 @@ int lumahip_build_lut(int ptf, unsigned bitdepth, float maxLum, float minLum, fl
 int lumahip_ycbcr_half_table_host(float sc, float maxLum, float *out, size_t cap);
 int lumahip_half_table_info(lumahip_ctx *ctx, float sc, int info[6]);
 
+/* Red / blue tables of the YCbCr decode kernels.  A decoded pixel's red depends on its luminance code and its Cr code only, its
+ * blue on the luminance code and the Cb code (src/luma_quantizer.cpp:447-451, 460-468: y + chroma term, clamp, PQdec, / sc), so per
+ * stream and preScaling the library tabulates both on the device (2 x 2^(bitdepth + bitdepthC) floats: 8 MiB for the HDR10
+ * recipe; only while that stays within 16 MiB; built by one launch with the same complete functions the kernels fall back to)
+ * and the kernels replace four of a pixel's six powf by two 4-byte gathers from global memory (L1 / L2) -- where the gathers are
+ * cheap: a wave first checks that most of its lanes' codes are close to their neighbours' (a picture), else it
+ * computes all three channels as before.  Results are identical either way.  lumahip_tune("ycbcr_rb_tables", v): 0 = never,
+ * 1 (default) = as described, and launches none of whose waves found its codes local send the following 16 eligible launches to
+ * the kernels without the test, then one launch probes again (the same data-driven policy as "half_table": per-launch feedback
+ * words read after the launch's completion event; the pause doubles up to 64 launches here), 2 = every wave takes the tables.
+ * lumahip_tune("rb_near_y" / "rb_near_c", n) = the closeness bounds of mode 1 in luminance / colour codes (64 / 24).
+ * lumahip_rb_table_info: info[0] = 1 when decode launches of this context and preScaling are eligible, info[1] = bytes of the two
+ * tables, info[2] = launches that took the kernels with the tables so far, info[3] = eligible launches the policy sent to the
+ * plain kernels instead. */
+int lumahip_rb_table_info(lumahip_ctx *ctx, float sc, int info[4]);
+
 /* Host-only (no GPU, no context): LumaQuantizer::quantize / dequantize for ONE value (src/luma_quantizer.cpp:215-264) on a
  * table of lut_len = 2^bitdepth floats -- the reference's literal bisection + nearest-of-two for channel 0 (and for every
  * channel of the RGB / XYZ colour spaces), clamp(floor(maxC*val + 0.5f), 0, maxC) resp. std::max(val/maxC, 1e-10f) for the
@@ -143,8 +159,10 @@ int lumahip_dequantize_value_host(const float *lut, size_t lut_len, int colorspa
 
 /* introspection of the search index built for the current LUT (tests):
  * info[0] = mode (0 = literal bisection, table in LDS; 2 = literal bisection, table read from global memory
- *                 (bitdepth > 12); 3 = threshold records in LDS; 4 = threshold records in global memory),
- * info[1] = mantissa bits of the record key, info[2] = number of records, info[3] = key shift,
+ *                 (bitdepth > 12); 3 = threshold records in LDS; 4 = threshold records in global memory;
+ *                 7 = value-keyed records in LDS: evenly spaced tables such as PTF_LINEAR, whose float-bit records
+ *                 would miss LDS -- lumahip_tune("lin_index", 0) keeps mode 4 for them),
+ * info[1] = mantissa bits of the record key (0 for mode 7), info[2] = number of records, info[3] = key shift (0 for mode 7),
  * info[4] = LDS bytes per workgroup of the encode-side kernels */
 int lumahip_quantizer_info(const lumahip_ctx *ctx, int info[5]);
 
@@ -432,6 +450,14 @@ int lumahip_multi_sync(lumahip_multi *m);
  * decreasing or duplicate entries, too many records) and the kernels run the literal bisection instead.
  * rec_out (nullable, rec_cap entries) receives the records. */
 int lumahip_thresh_index_host(const float *lut, size_t n, int info[5], uint32_t *rec_out, size_t rec_cap);
+
+/* Host-only (no GPU, no context): the VALUE-keyed records of a monotone finite table whose thresholds are (about) evenly
+ * spaced (PTF_LINEAR, src/luma_quantizer.cpp:200-203; lumahdrv_amd/csrc/lut_index.hpp LinIndex):
+ * key = (uint32)max(fminf(v * kscale, nbuckets - 1), 0) with the product rounded to fp32, rec[2 key] = P (the bit pattern just
+ * below the bucket's threshold; 0x7fffffff: none), rec[2 key + 1] = start, quantize(v) = start + ((int32)bits(v) > (int32)P) for
+ * EVERY float.  info = {ok, nbuckets, the bits of
+ * kscale}; ok = 0 when no scale keeps two thresholds apart within 32768 buckets (PQ, LOG: their thresholds crowd near zero). */
+int lumahip_lin_index_host(const float *lut, size_t n, int info[3], uint32_t *rec_out, size_t rec_cap);
 
 /* Host-only (no GPU, no context): the two per-stream tables of the YCbCr kernels, built with the host libm as the reference
  * would evaluate them per pixel.  (1) The threshold records -- same format and lookup as lumahip_thresh_index_host, for

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 
 SYMBOLS = [
     "lumahip_abi_version", "lumahip_device_count", "lumahip_create", "lumahip_destroy", "lumahip_last_error",
-    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_half_upload_info", "lumahip_numa_info", "lumahip_numa_pin_current_thread", "lumahip_numa_plan_host", "lumahip_quantizer_info",
+    "lumahip_set_stream", "lumahip_reset_stream", "lumahip_sync", "lumahip_tune", "lumahip_set_quantizer", "lumahip_build_lut", "lumahip_thresh_index_host", "lumahip_lin_index_host", "lumahip_ycbcr_luma_index_host", "lumahip_ycbcr_ytab_host", "lumahip_ycbcr_half_table_host", "lumahip_half_table_info", "lumahip_rb_table_info", "lumahip_quantize_value_host", "lumahip_dequantize_value_host", "lumahip_half_upload_info", "lumahip_numa_info", "lumahip_numa_pin_current_thread", "lumahip_numa_plan_host", "lumahip_quantizer_info",
     "lumahip_encode_stream_push", "lumahip_encode_stream_pop", "lumahip_encode_stream_pending",
     "lumahip_decode_stream_push", "lumahip_decode_stream_pop", "lumahip_decode_stream_pending",
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
@@ -120,11 +120,13 @@ def lib():
     L.lumahip_set_quantizer.argtypes = [vp, i, u, i, u, f, f, vp, sz]
     L.lumahip_build_lut.argtypes = [i, u, f, f, vp, sz]
     L.lumahip_thresh_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
+    L.lumahip_lin_index_host.argtypes = [vp, sz, C.POINTER(i), vp, sz]
     L.lumahip_quantizer_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_ycbcr_luma_index_host.argtypes = [vp, sz, f, C.POINTER(i), vp, sz]
     L.lumahip_ycbcr_ytab_host.argtypes = [vp, sz, f, vp]
     L.lumahip_ycbcr_half_table_host.argtypes = [f, f, vp, sz]
     L.lumahip_half_table_info.argtypes = [vp, f, C.POINTER(i)]
+    L.lumahip_rb_table_info.argtypes = [vp, f, C.POINTER(i)]
     L.lumahip_half_upload_info.argtypes = [vp, C.POINTER(C.c_long)]
     L.lumahip_numa_info.argtypes = [vp, C.POINTER(i)]
     L.lumahip_numa_pin_current_thread.argtypes = [vp]
@@ -267,6 +269,34 @@ def thresh_index(lut: np.ndarray):
     return d
 
 
+def lin_index(lut: np.ndarray):
+    """host-only: the value-keyed records of an evenly spaced table (include/lumahip.h lumahip_lin_index_host); no GPU needed.
+    dict(ok, nbuckets, kscale (np.float32), rec (nbuckets x 2 uint32: bits(T) - 1, start) | None)"""
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    info = (C.c_int * 3)()
+    rc = lib().lumahip_lin_index_host(lut.ctypes.data, lut.size, info, None, 0)
+    if rc != OK:
+        raise LumaHipError(rc, "lumahip_lin_index_host failed")
+    d = dict(ok=bool(info[0]), nbuckets=info[1], kscale=np.array([info[2]], dtype=np.int32).view(np.float32)[0], rec=None)
+    if d["ok"]:
+        rec = np.zeros((info[1], 2), dtype=np.uint32)
+        rc = lib().lumahip_lin_index_host(lut.ctypes.data, lut.size, info, rec.ctypes.data, rec.size)
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_lin_index_host failed")
+        d["rec"] = rec
+    return d
+
+
+def lin_lookup(ix, v: np.ndarray) -> np.ndarray:
+    """numpy evaluation of value-keyed records, as the kernels evaluate them (luma_device.hpp quantize_linkey)"""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        p = np.fmin(v * np.float32(ix["kscale"]), np.float32(ix["nbuckets"] - 1))      # fmin: a NaN product -> the top bucket
+        k = np.where(p > 0, p, np.float32(0)).astype(np.int64)                            # truncation; negatives and -0 -> 0
+    rec = ix["rec"]
+    return rec[k, 1].astype(np.int64) + (v.view(np.int32) > rec[k, 0].view(np.int32)).astype(np.int64)
+
+
 def ycbcr_luma_index(lut: np.ndarray, max_lum: float):
     """host-only: the composite luma -> luminance code records of the YCbCr encode kernels (same dict as thresh_index)"""
     lut = np.ascontiguousarray(lut, dtype=np.float32)
@@ -403,6 +433,11 @@ class Context:
         a = (C.c_int * 3)()
         self._chk(self.L.lumahip_numa_info(self.h, a))
         return dict(node=a[0], cpus=a[1], first_cpu=a[2])
+
+    def rb_table_info(self, sc: float):
+        a = (C.c_int * 4)()
+        self._chk(self.L.lumahip_rb_table_info(self.h, sc, a))
+        return dict(used=bool(a[0]), bytes=a[1], table_launches=a[2], backoff_launches=a[3])
 
     def half_table_info(self, sc: float):
         a = (C.c_int * 6)()

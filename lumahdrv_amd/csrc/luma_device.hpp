@@ -594,6 +594,54 @@ LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float 
     }
 }
 
+// The same with red and blue NOT evaluated in the straight-line code: the decode kernels with the per-stream (Y', Cb) -> blue and
+// (Y', Cr) -> red tables (luma_kernels.hpp, RB) read those two channels from global memory and compute green only -- it depends on
+// all three codes.  c0 = y (the y table), c1 / c2 = the chroma TERMS (CT form of ycbcr_inv).  Returns true when the unit took
+// the complete functions (bad code, or green's arguments left the licensed ranges); r, g, b then hold all three results and the
+// caller drops what it gathered.
+template <int N, int SCDIV, int NC, bool SUB, typename K>
+LH_DEV bool ycbcr_inv_green_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
+                              float (&g)[N], float (&b)[N], const int (&code1)[NC], const int (&code2)[NC], float maxC, bool bad_code)
+{
+    constexpr int ELIM = SCDIV == 1 ? 56 : 1;
+    SlowAcc slow;
+    slow.flag = !(k.Lmax >= 1e-6f && k.Lmax <= 1e9f) || (SCDIV == 0 && k.sc_mode == 2) || bad_code;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float y = c0[i];
+        const float blue = y + c1[i], red = y + c2[i];
+        float green = div_nr_r((y - 0.2627f * red) - 0.0593f * blue, 0.6780f, k.r0678);
+        green = std_max(0x1p-21f, std_min(1.0f, green));   // (see ycbcr_inv on the lower bound)
+        g[i] = pq_decode_r<false, true, ELIM>(green, k, slow);
+        if constexpr (SCDIV == 1)
+            g[i] = div_nr_r(g[i], k.sc, k.rsc);
+    }
+    const bool redo = slow_any(slow, k);
+    if (__builtin_expect(redo, 0)) {
+        for (int i = 0; i < N; i++) {  // not unrolled: cold code
+            const int j = SUB ? (i % (N / 2)) / 2 : i;
+            const float d1 = dequantize_color_ieee(pick(code1, j), maxC), d2 = dequantize_color_ieee(pick(code2, j), maxC);
+            ycbcr_inv<false, true>(c0[i], d1, d2, k, r[i], g[i], b[i], slow);
+            r[i] = div_ieee(r[i], k.sc);   // (x / 1.0f == x)
+            g[i] = div_ieee(g[i], k.sc);
+            b[i] = div_ieee(b[i], k.sc);
+        }
+    }
+    return redo;
+}
+
+// One entry of the per-stream red / blue tables: what the reference makes of luminance code `ycode` and colour code `ccode`
+// (src/luma_quantizer.cpp:253-261 dequantize, :447-451 y and the chroma term, :460-468 clamp, PQdec, / sc) with the complete
+// functions and IEEE division throughout -- the arithmetic every straight-line form above is checked against.
+// coef = 1.8814f (blue from Cb) or 1.4746f (red from Cr); yval = the y table's entry of the luminance code.
+template <typename K>
+LH_DEV float ycbcr_rb_entry(float yval, int ccode, float maxC, float coef, const K &k)
+{
+    const float v = yval + ycbcr_chroma_term(ccode, maxC, coef);
+    const float cl = std_max(0.0f, std_min(1.0f, v));
+    return div_ieee(pq_decode(cl, k), k.sc);
+}
+
 template <int N, bool YT = false, int SCDIV = 0, typename K>
 LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float (&c2)[N], const K &k, float (&r)[N],
                         float (&g)[N], float (&b)[N])
@@ -722,6 +770,7 @@ struct QuantDev {
     int maxVal;
     int mode;                // lh::LutMode
     int shift, kmin, nbuckets;  // threshold records: key = bits >> shift, clamped to [kmin, kmin+nbuckets-1]
+    float kscale;            // value-keyed records (mode 7, lut_index.hpp LinIndex): key = cvt_u32(min(v * kscale, nbuckets - 1))
     float maxC;              // (float)m_maxValColor
     int cs;
     float Lmax;
@@ -858,13 +907,40 @@ LH_DEV void quantize_thresh(const float (&v)[N], int (&code)[N], RecPtr rec, con
     }
 }
 
+// Value-keyed records (lut_index.hpp LinIndex; evenly spaced tables, PTF_LINEAR): rec[key] = {P, start}, P = bits(T) - 1,
+// code = start + ((int)bits(v) > (int)P), key = cvt_u32(min(v * kscale, nbuckets - 1)).  The product is one rounded fp32
+// operation exactly as the host evaluated it when it sorted the thresholds into buckets; v_min_f32 returns the non-NaN
+// operand, so a NaN (the product quiets a signalling one) lands in the top bucket, whose start is maxVal and whose P = 0x7fffffff no
+// signed integer exceeds -- the reference's answer for every NaN; v_cvt_u32_f32 truncates and saturates negatives to 0,
+// and in bucket 0 the SIGNED comparison is false for every negative float (sign bit set): code c0.  One 8-byte gather.
+template <int N, typename RecPtr>
+LH_DEV void quantize_linkey(const float (&v)[N], int (&code)[N], RecPtr rec, const QuantDev &q)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const float top = (float)(q.nbuckets - 1);
+    u32x2 r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float p = __builtin_fminf(v[i] * q.kscale, top);
+        uint32_t k;
+        asm("v_cvt_u32_f32 %0, %1" : "=v"(k) : "v"(p));   // (a C++ cast of a negative float is undefined; the instruction saturates)
+        r[i] = *reinterpret_cast<const u32x2 *>(rec + 2 * k);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        code[i] = (int)r[i].y + (__float_as_int(v[i]) > (int)r[i].x ? 1 : 0);
+}
+
 // MODE (lut_index.hpp LutMode): 0 literal bisection (table in LDS), 2 literal bisection (table in global memory),
 //       3 / 4 threshold records (LDS / global); `idx` = the records for 3 / 4, unused otherwise;
-//       5 = records (LDS) of the YCbCr composite t -> code (ycbcr_fwd<., YCODE>): v is t = 219 y + 16, >= 16 or NaN
+//       5 = records (LDS) of the YCbCr composite t -> code (ycbcr_fwd<., YCODE>): v is t = 219 y + 16, >= 16 or NaN;
+//       7 = value-keyed records in LDS (quantize_linkey)
 template <int MODE, int N, bool NONNEG = false, typename LutPtr, typename IdxPtr>
 LH_DEV void quantize_lut(const float (&v)[N], int (&code)[N], LutPtr lut, IdxPtr idx, const QuantDev &q)
 {
-    if constexpr (MODE == 5) {
+    if constexpr (MODE == 7) {
+        quantize_linkey<N>(v, code, idx, q);
+    } else if constexpr (MODE == 5) {
         quantize_thresh<N, true>(v, code, idx, q);
     } else if constexpr (MODE == 3 || MODE == 4) {
         quantize_thresh<N, NONNEG>(v, code, idx, q);

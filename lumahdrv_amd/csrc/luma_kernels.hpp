@@ -76,6 +76,17 @@ struct DecArgs {
     size_t disp_frame_stride;
     float exposure, inv_gamma;
     int do_tmo, ldr_sim;
+    // YCbCr decode with the per-stream red / blue tables (k_decode<..., RB>): rb[cb * lut_len + ycode] = blue,
+    // rb[rb_plane + cr * lut_len + ycode] = red, final values (after / sc) of this call's preScaling; global memory (L2 / MALL)
+    const float *rb;
+    size_t rb_plane;
+    // a wave takes the gathers for a unit only when most of its lanes' codes are close to each other and to their neighbour
+    // lane's (rb_wave_local): luminance codes within rb_near_y, colour codes within rb_near_c; negative rb_near_y: always
+    int rb_near_y, rb_near_c;
+    // nullable: THIS launch's word in host-visible memory, set to 1 by every workgroup in which some wave took the tables for some
+    // unit -- a launch that leaves it 0 found none of its pixels local, and the host sends the next launches to the kernels
+    // without the test (lumahip_internal.hpp LagPolicy).  Feedback only.
+    uint32_t *rb_flag;
 };
 
 // LDS layout: [powf tables (YCbCr only; FIRST, so that their addresses are immediates in the powf chains)]
@@ -108,7 +119,7 @@ LH_DEV void stage_powf_tables(PowfTablesWide *t)
 }
 
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }
-LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * 4 + 15) & ~15; }
+LH_DEV int lds_rec_bytes(const QuantDev &q) { return (q.nbuckets * (q.mode == 7 ? 8 : 4) + 15) & ~15; }   // (7: {T, start} pairs)
 
 // offset of the search table / records behind the powf tables
 template <int WHAT>
@@ -327,7 +338,7 @@ LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 
 // ---- ENCODE ---------------------------------------------------------------------------------------
 // CS: colour space; SUB: 4:2:0 (profiles 0/2) vs 4:4:4 (1/3); VW: pixels per thread per row (4 or 2);
-// LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global;
+// LM: luminance search mode (lut_index.hpp LutMode: 0 literal/LDS, 2 literal/global, 3 records/LDS, 4 records/global, 7 value-keyed records/LDS;
 // 5 = YCbCr only: records in LDS for the composite luma -> code function, channel 0 carries the luma y, luma_device.hpp ycbcr_fwd;
 // 6 = 5 + the half-input table in LDS: R', G', B' are three gathers for pixels whose inputs are binary16 values, luma_device.hpp half_lookup).
 //
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
     __shared__ int s_votes[HALF ? 2 : 1];   // HALF: waves of this workgroup that had units / that left the table in every one
     if (HALF && threadIdx.x == 0)
         s_votes[0] = s_votes[HALF ? 1 : 0] = 0;   // (stage_tables synchronises)
-    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 5 || LM == 6) ? STAGE_REC : 0) |
+    constexpr int WHAT = (LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 5 || LM == 6 || LM == 7) ? STAGE_REC : 0) |
                          (CS == CS_YCBCR ? (HALF ? STAGE_POWFN | STAGE_HALF : STAGE_POWF) : 0);
     stage_tables<WHAT>(smem, a.q, a.half);
 
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(EncWaves<C
         if (valid) {
             if constexpr (LM == 6)
                 enc_emit<CS, SUB, VW, 5>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
-            else if constexpr (LM == 3 || LM == 5)
+            else if constexpr (LM == 3 || LM == 5 || LM == 7)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, s_lut, s_rec);
             else if constexpr (LM == 4)
                 enc_emit<CS, SUB, VW, LM>(f, ux, uy, c0, c1, c2, a, a.q.lut, a.q.rec);
@@ -698,10 +709,55 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
-// SCFAST (YCbCr): the straight-line code divides by sc with the short division (XformConst::sc_mode == 1, ycbcr_inv_n)
-template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, bool SCFAST = false, typename LutPtr, typename K>
-LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k, LutPtr lut, const float *s_uv)
+// Whether this wave reads red and blue of the current unit from the per-stream tables (k_decode<..., RB>) or computes them.
+// What a gather costs is decided by the CU's 32 KiB vector L1 (profiles/r05_ycbcr_decode_tables.txt, TCP_TCC_READ_REQ): a
+// table line holds 32 consecutive luminance codes of ONE colour code; with the codes of a picture a lane's eight pixels read
+// two lines per table, its neighbours and the rows above and below read the same ones, 99 % of the lanes hit the L1 and the
+// launch takes 0.80 ms per 20 x 4K against 1.23 for six powf per pixel.  With unrelated codes in every pixel (the synthetic
+// stream of SURVEY 8(d)) every lane of every gather is its own L2 request -- 3.2e8 per launch, the L2's request rate -- and the
+// same launch takes 1.84 ms.  So a wave looks at its codes first, per unit, wave-uniformly (no divergence), ~20 instructions:
+// a lane is "local" when its eight luminance codes lie within `near_y` of each other, its first luminance code within near_y
+// of its left neighbour lane's, and its first colour codes within near_c (|dCb| + |dCr|) of that neighbour's; the wave gathers
+// when at least RB_LOCAL_LANES of its lanes are.  Whichever path runs, the results are the same bits.
+constexpr int RB_LOCAL_LANES = 48;
+
+LH_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc)
 {
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));   // |a - b| + acc
+    return r;
+}
+
+// the value of lane - 1 (lane 0: 0)
+LH_DEV uint32_t left_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+
+template <bool SUB, int VW>
+LH_DEV bool rb_wave_local(const DecUnit<SUB, VW> &u, int near_y, int near_c)
+{
+    if (near_y < 0)
+        return true;
+    int lo = u.y[0][0], hi = u.y[0][0];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < VW; i++) {
+            lo = min(lo, u.y[r][i]);
+            hi = max(hi, u.y[r][i]);
+        }
+    const uint32_t y0 = (uint32_t)u.y[0][0], b0 = (uint32_t)u.c1[0], r0 = (uint32_t)u.c2[0];
+    const uint32_t dy = sad_u32(y0, left_lane(y0), 0u);
+    const uint32_t dc = sad_u32(r0, left_lane(r0), sad_u32(b0, left_lane(b0), 0u));
+    const bool local = (hi - lo) <= near_y && dy <= (uint32_t)near_y && dc <= (uint32_t)near_c;
+    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(local)) >= RB_LOCAL_LANES;
+}
+
+// SCFAST (YCbCr): the straight-line code divides by sc with the short division (XformConst::sc_mode == 1, ycbcr_inv_n)
+// Returns (RB only; wave-uniform) whether the wave took red and blue of this unit from the tables.
+template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, bool SCFAST = false, bool RB = false, typename LutPtr, typename K>
+LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k, LutPtr lut, const float *s_uv)
+{
+    bool gathered = false;
+    static_assert(!RB || (YT && CS == CS_YCBCR), "the red / blue tables belong to the YCbCr kernels with the y table");
     constexpr bool LUT_ALL = (CS == CS_RGB || CS == CS_XYZ);
     const float maxC = a.q.maxC;
     const int maxVal = a.q.maxVal;
@@ -775,7 +831,35 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k,
                     c2[j] = t2;
                 }
             }
-            ycbcr_inv_n<2 * VW, true, SCFAST ? 1 : 0, true, NC, SUB>(c0, c1, c2, k, r8, g8, b8, u.c1, u.c2, maxC, bad);
+            bool gather = false;
+            if constexpr (RB)
+                gather = rb_wave_local<SUB, VW>(u, a.rb_near_y, a.rb_near_c);   // wave-uniform
+            gathered = gather;
+            if (RB && gather) {
+                // red and blue of every pixel from the per-stream tables: two 4-byte gathers from global memory, issued before
+                // green's two powf chains (which cover their latency); plain loads -- these lines are worth caching
+                float tr[2 * VW], tb[2 * VW];
+                const size_t n = (size_t)a.q.lut_len;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int i = 0; i < VW; i++) {
+                        const int j = SUB ? i / 2 : r * VW + i;
+                        const size_t yc = (size_t)min(u.y[r][i], maxVal);
+                        tb[r * VW + i] = a.rb[(size_t)min(u.c1[j], maxCi) * n + yc];
+                        tr[r * VW + i] = a.rb[a.rb_plane + (size_t)min(u.c2[j], maxCi) * n + yc];
+                    }
+                const bool redo = ycbcr_inv_green_n<2 * VW, SCFAST ? 1 : 0, NC, SUB>(c0, c1, c2, k, r8, g8, b8, u.c1, u.c2, maxC, bad);
+                if (!redo) {
+#pragma unroll
+                    for (int j = 0; j < 2 * VW; j++) {
+                        r8[j] = tr[j];
+                        b8[j] = tb[j];
+                    }
+                }
+            } else {
+                ycbcr_inv_n<2 * VW, true, SCFAST ? 1 : 0, true, NC, SUB>(c0, c1, c2, k, r8, g8, b8, u.c1, u.c2, maxC, bad);
+            }
         } else {
             ycbcr_inv_n<2 * VW, YT, SCFAST ? 1 : 0>(c0, c1, c2, k, r8, g8, b8);
         }
@@ -847,16 +931,19 @@ LH_DEV void dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k,
                 reinterpret_cast<uint32_t *>(d)[i] = px[i];
         }
     }
+    return gathered;
 }
 
 // DISP: additionally (or only) emit the RGBA8 display image -- a separate instantiation so that the plain
 // decoder does not carry the epilogue's registers (it cost 8 % when it was a run-time branch)
 // YT (YCbCr, table in LDS): additionally stage the per-stream y table and skip the first PQ evaluation of every pixel
-template <int CS, bool SUB, int VW, bool GL, bool DISP = false, bool YT = false>
+// RB (with YT): red and blue from the per-stream (Y', Cr) / (Y', Cb) tables in global memory, green computed (DecArgs::rb)
+template <int CS, bool SUB, int VW, bool GL, bool DISP = false, bool YT = false, bool RB = false>
 __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(!YT || (CS == CS_YCBCR && !GL), "the y table belongs to the YCbCr kernels with the table in LDS");
+    static_assert(!RB || YT, "the red / blue tables need the y table");
     // GL: transfer-function table or chroma depth beyond 12 bits -- tables stay in global memory / are not built
     constexpr bool UVTAB = (CS == CS_LUV && !GL);
     // (The 16-entry powf tables instead -- no LDS bank conflicts, ten more issue cycles per powf -- were tried for this kernel
@@ -872,6 +959,10 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     const int NW = blockDim.x >> 6;
     const int G = gridDim.x;
 
+    __shared__ int s_gathered[RB ? 1 : 1];
+    if (RB && threadIdx.x == 0)
+        s_gathered[0] = 0;   // (stage_tables has synchronised already; the one reader waits at the barrier at the end)
+    bool any_gather = false;
     DecUnit<SUB, VW> cur, nxt;
     dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
@@ -882,12 +973,12 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
                     if constexpr (GL)
                         dec_process<CS, SUB, VW, DISP, false, false, true>(cur, a, k, a.q.lut, s_uv);
                     else
-                        dec_process<CS, SUB, VW, DISP, UVTAB, YT, true>(cur, a, k, s_lut, s_uv);
+                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, true, RB>(cur, a, k, s_lut, s_uv);
                 } else {
                     if constexpr (GL)
                         dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
                     else
-                        dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv);
+                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, false, RB>(cur, a, k, s_lut, s_uv);
                 }
             } else if constexpr (GL) {
                 dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
@@ -899,6 +990,15 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)
         dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         cur = nxt;
+    }
+    if constexpr (RB) {
+        if (a.rb_flag) {   // (kernel argument: uniform)
+            if (any_gather)
+                s_gathered[0] = 1;   // (same value from every writer)
+            __syncthreads();
+            if (threadIdx.x == 0 && s_gathered[0])
+                __hip_atomic_store(a.rb_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -990,7 +1090,7 @@ template <int LM, bool NONNEG>
 __global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16_t *out, uint32_t first_bits, size_t n4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    stage_tables<(LM == 0 ? STAGE_LUT : 0) | (LM == 3 ? STAGE_REC : 0)>(smem, q);
+    stage_tables<(LM == 0 ? STAGE_LUT : 0) | ((LM == 3 || LM == 7) ? STAGE_REC : 0)>(smem, q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
     const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -999,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_quantize_probe(const QuantDev q, uint16
 #pragma unroll
         for (int j = 0; j < 4; j++)
             v[j] = __uint_as_float(first_bits + (uint32_t)(4 * i + j));
-        if constexpr (LM == 3)
+        if constexpr (LM == 3 || LM == 7)
             quantize_lut<LM, 4, NONNEG>(v, c, s_lut, s_rec, q);
         else if constexpr (LM == 4)
             quantize_lut<LM, 4, NONNEG>(v, c, q.lut, q.rec, q);

@@ -89,11 +89,10 @@ extern "C" void lumahip_destroy(lumahip_ctx *c)
     (void)hipFree(c->d_ytab);
     for (auto &t : c->half_tabs)
         (void)hipFree(t.d);
-    if (c->h_half_flag) {
-        for (auto &e : c->half_ev)
-            if (e) (void)hipEventDestroy(e);
-        (void)hipHostFree(c->h_half_flag);
-    }
+    for (auto &t : c->rb_tabs)
+        (void)hipFree(t.d);
+    lag_policy_destroy(c->half_pol);
+    lag_policy_destroy(c->rb_pol);
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_planes);
     (void)hipFree(c->d_stats);
@@ -231,7 +230,7 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         return LUMAHIP_ERR_ARG;
     const std::string k(key);
     // the keys that rebuild the device tables: not under frames pushed with the stream entry points (as lumahip_set_quantizer)
-    if ((k == "lds_table_max_kb" || k == "force_literal" || k == "ycbcr_tables") && c->es_head != c->es_tail)
+    if ((k == "lds_table_max_kb" || k == "force_literal" || k == "ycbcr_tables" || k == "lin_index") && c->es_head != c->es_tail)
         return fail(c, LUMAHIP_ERR_STATE, "frames pushed with lumahip_encode_stream_push / lumahip_decode_stream_push are still in flight: pop them before '%s'", key);
     if (k == "block") {
         if (v == 0) {
@@ -268,6 +267,19 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         c->use_ycbcr_tables = v != 0;
         if (c->have_quant)
             return requantize(c);
+    } else if (k == "ycbcr_rb_tables") {
+        if (v < 0 || v > 2)
+            return fail(c, LUMAHIP_ERR_ARG, "ycbcr_rb_tables must be 0 (six powf per pixel), 1 (red and blue from the per-stream tables where a wave's codes are close) or 2 (always)");
+        c->rb_mode = (int)v;
+        lag_policy_reset(c->rb_pol);
+    } else if (k == "rb_near_y") {
+        c->rb_near_y = (int)std::max<long>(0, std::min<long>(v, 1 << 24));
+    } else if (k == "rb_near_c") {
+        c->rb_near_c = (int)std::max<long>(0, std::min<long>(v, 1 << 24));
+    } else if (k == "lin_index") {   // 0: tables whose float-bit records miss LDS keep them in global memory, as before round 5 (A/B, tests)
+        c->use_lin_index = v != 0;
+        if (c->have_quant)
+            return requantize(c);
     } else if (k == "numa" || k == "numa_node") {
         // takes effect for what is allocated / started from now on: set it before the first host call of a context
         if (k == "numa")
@@ -286,7 +298,7 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
         if (v < 0 || v > 2)
             return fail(c, LUMAHIP_ERR_ARG, "half_table must be 0 (off), 1 (while the stream is binary16 data) or 2 (always)");
         c->half_mode = (int)v;
-        half_policy_reset(c);
+        lag_policy_reset(c->half_pol);
     } else if (k == "host_bands") {
         if (v < 1 || v > lumahip_ctx::MAX_BANDS)
             return fail(c, LUMAHIP_ERR_ARG, "host_bands must be 1..%d", lumahip_ctx::MAX_BANDS);
@@ -345,6 +357,27 @@ std::shared_ptr<const ThreshIndex> cached_thresh_index(const std::vector<float> 
     g_index_cache.push_back(e);
     return e.ix;
 }
+struct LinCacheEntry {
+    std::vector<float> lut;
+    std::shared_ptr<const LinIndex> ix;
+};
+std::vector<LinCacheEntry> g_lin_cache;
+
+// value-keyed records (lut_index.hpp LinIndex) of a table whose float-bit records do not fit LDS
+std::shared_ptr<const LinIndex> cached_lin_index(const std::vector<float> &lut)
+{
+    std::lock_guard<std::mutex> lk(g_index_mutex);
+    for (auto &e : g_lin_cache)
+        if (e.lut.size() == lut.size() && memcmp(e.lut.data(), lut.data(), lut.size() * sizeof(float)) == 0)
+            return e.ix;
+    LinCacheEntry e;
+    e.lut = lut;
+    e.ix = std::make_shared<const LinIndex>(build_lin_index(lut.data(), (int)lut.size(), 1 << 15));
+    if (g_lin_cache.size() >= 8)
+        g_lin_cache.erase(g_lin_cache.begin());
+    g_lin_cache.push_back(e);
+    return e.ix;
+}
 struct YIndexCacheEntry {
     std::vector<float> lut;
     float Lmax;
@@ -392,6 +425,9 @@ static int upload_table(lumahip_ctx *c)
     c->d_rec = nullptr;
     c->d_rec_y = nullptr;
     c->d_ytab = nullptr;
+    for (auto &t : c->rb_tabs)     // (the red / blue tables of the YCbCr decode kernels were built from the old y table)
+        (void)hipFree(t.d);
+    c->rb_tabs.clear();
     c->tix_y.reset();
     HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -457,6 +493,27 @@ int lhost::ensure_search_index(lumahip_ctx *c)
             q.shift = ix.shift;
             q.kmin = ix.kmin;
             q.nbuckets = ix.nbuckets;
+            q.kscale = 0.0f;
+            if (q.mode == LUT_THRESH_GLOBAL && c->use_lin_index) {
+                // float-bit records too large for LDS: an evenly spaced table (PTF_LINEAR) fits when its records are keyed by
+                // VALUE instead (lut_index.hpp LinIndex: LINEAR-12 32 KiB against 229 KiB)
+                c->lix = cached_lin_index(c->h_lut);
+                const LinIndex &lx = *c->lix;
+                if (lx.ok && lx.rec.size() * 4 <= c->lds_table_max && lx.rec.size() * 4 + 16 + powf_b <= LUMAHIP_LDS_PER_WORKGROUP) {
+                    std::vector<uint32_t> rl((lx.rec.size() + 3) & ~(size_t)3, 0u);
+                    memcpy(rl.data(), lx.rec.data(), lx.rec.size() * sizeof(uint32_t));
+                    (void)hipFree(c->d_rec);
+                    c->d_rec = nullptr;
+                    HIPCHK(c, hipMalloc(&c->d_rec, rl.size() * sizeof(uint32_t)));
+                    HIPCHK(c, hipMemcpy(c->d_rec, rl.data(), rl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    q.rec = c->d_rec;
+                    q.mode = LUT_LINKEY_LDS;
+                    q.shift = 0;
+                    q.kmin = 0;
+                    q.nbuckets = lx.nbuckets;
+                    q.kscale = lx.kscale;
+                }
+            }
             // YCbCr encode: the luminance code straight from the luma y (composite records; luma_device.hpp ycbcr_fwd<., YCODE>)
             if (q.cs == CS_YCBCR && c->use_ycbcr_tables && q.mode == LUT_THRESH_LDS) {
                 c->tix_y = cached_ycbcr_index(c->h_lut, q.Lmax);
@@ -506,7 +563,8 @@ extern "C" int lumahip_set_quantizer(lumahip_ctx *c, int ptf, unsigned bitdepth,
     // src/luma_quantizer.cpp:181); the transform entry points then fail the way transformColorSpace does.
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    half_policy_reset(c);   // a new stream: the half-input policy starts afresh
+    lag_policy_reset(c->half_pol);   // a new stream: the kernel-choice policies start afresh
+    lag_policy_reset(c->rb_pol);
     c->have_quant = false;
     c->h_lut.assign(lut, lut + n);
     c->q.maxC = (float)(((unsigned)1 << bitdepthC) - 1);     // src/luma_quantizer.cpp:183
@@ -542,6 +600,23 @@ extern "C" int lumahip_thresh_index_host(const float *lut, size_t n, int info[5]
     return LUMAHIP_OK;
 }
 
+// host-only view of the value-keyed records (no GPU, no context): info = {ok, nbuckets, bits of kscale}; rec_out: 2 words per bucket
+extern "C" int lumahip_lin_index_host(const float *lut, size_t n, int info[3], uint32_t *rec_out, size_t rec_cap)
+{
+    if (!lut || !info || n < 2 || n > 65536)
+        return LUMAHIP_ERR_ARG;
+    const LinIndex ix = build_lin_index(lut, (int)n, 1 << 15);
+    info[0] = ix.ok ? 1 : 0;
+    info[1] = ix.nbuckets;
+    memcpy(&info[2], &ix.kscale, sizeof(float));
+    if (rec_out && ix.ok) {
+        if (rec_cap < ix.rec.size())
+            return LUMAHIP_ERR_ARG;
+        memcpy(rec_out, ix.rec.data(), ix.rec.size() * sizeof(uint32_t));
+    }
+    return LUMAHIP_OK;
+}
+
 extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
 {
     if (!c || !info)
@@ -554,9 +629,9 @@ extern "C" int lumahip_quantizer_info(const lumahip_ctx *c, int info[5])
         return rc;
     const bool ok = c->tix && c->tix->ok;
     info[0] = c->q.mode;
-    info[1] = ok ? c->tix->mant_bits : 0;
+    info[1] = (ok && c->q.mode != LUT_LINKEY_LDS) ? c->tix->mant_bits : 0;
     info[2] = c->q.nbuckets;
-    info[3] = ok ? c->tix->shift : 0;
+    info[3] = (ok && c->q.mode != LUT_LINKEY_LDS) ? c->tix->shift : 0;
     info[4] = (int)lds_bytes(c, true, c->q.cs);
     return LUMAHIP_OK;
 }
@@ -690,7 +765,7 @@ extern "C" int lumahip_half_table_info(lumahip_ctx *c, float sc, int info[6])
     for (const auto &t : c->half_tabs)
         info[2] += t.d != nullptr;
     info[4] = (int)std::min<unsigned long>(c->half_launches, 0x7fffffffUL);
-    info[5] = (int)std::min<unsigned long>(c->half_backoff_launches, 0x7fffffffUL);
+    info[5] = (int)std::min<unsigned long>(c->half_pol.backoff_launches, 0x7fffffffUL);
     return LUMAHIP_OK;
 }
 
@@ -765,113 +840,110 @@ extern "C" int lumahip_numa_pin_current_thread(lumahip_ctx *c)
     return LUMAHIP_OK;
 }
 
-// Which kernel an eligible launch takes (half_mode 1).  The half-input kernel evaluates units that hold anything but binary16
-// values with the general functions on top of its table reads -- 1.4 x the per-pixel kernels' time when EVERY pixel does that
-// (profiles/r04_half_miss_rate.txt), so a stream of full-precision floats (a PFS pipe rather than an EXR file) must not stay
-// on it.  A table launch whose workgroups all found nothing but non-half data in every unit writes 1 into ITS feedback word
-// (EncArgs::half_flag, a ring of HALF_RING words of pinned host memory); an event is recorded right behind it.  The word of
-// table launch j is read when the eligible launch HALF_LAG after it is issued, once j's event has completed (normally long
-// ago; at most HALF_LAG - 1 launches stay queued behind it, so the device does not run dry).  The policy is a function of
-// those words in that order, i.e. of the data alone -- the same stream takes the same kernels on every run:
-//   ON_TABLE    table launches; a report -> BACKOFF for 16 launches (reports of the other launches in flight are dropped);
-//   BACKOFF     per-pixel launches; when the count runs out, ONE table launch probes -> PROBE_WAIT;
-//   PROBE_WAIT  per-pixel launches until the probe's word is read (HALF_LAG launches later): a report -> BACKOFF with the pause
-//               doubled (up to 1024: one probe in a thousand launches costs 0.04 %), none -> ON_TABLE and the pause forgotten.
-void half_policy_reset(lumahip_ctx *c)
+// Kernel choice from feedback (lumahip_internal.hpp LagPolicy says what and why).
+void lag_policy_reset(LagPolicy &p)
 {
-    // reports of launches still in flight belong to the stream that ends here: wait for them, clear their words
-    for (const auto &p : c->half_pending) {
-        (void)hipEventSynchronize(c->half_ev[p.slot]);
-        __atomic_store_n(&c->h_half_flag[p.slot], 0u, __ATOMIC_RELAXED);
+    // words of launches still in flight belong to the stream that ends here: wait for them, clear them
+    for (const auto &q : p.pending) {
+        (void)hipEventSynchronize(p.ev[q.slot]);
+        __atomic_store_n(&p.h_flag[q.slot], 0u, __ATOMIC_RELAXED);
     }
-    c->half_pending.clear();
-    c->half_state = lumahip_ctx::HALF_ON_TABLE;
-    c->half_backoff = c->half_backoff_len = 0;
+    p.pending.clear();
+    p.state = LagPolicy::ON_FAST;
+    p.backoff = p.backoff_len = 0;
 }
 
-static void half_report(lumahip_ctx *c, const lumahip_ctx::HalfPending &p, bool reported)
+void lag_policy_destroy(LagPolicy &p)
 {
-    using X = lumahip_ctx;
-    if (c->half_state == X::HALF_ON_TABLE) {
-        if (reported) {
-            c->half_reports++;
-            c->half_backoff_len = 16;
-            c->half_backoff = c->half_backoff_len;
-            c->half_state = X::HALF_BACKOFF;
+    if (!p.h_flag)
+        return;
+    for (auto &e : p.ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipHostFree(p.h_flag);
+    p.h_flag = nullptr;
+}
+
+static void lag_policy_word(LagPolicy &p, const LagPolicy::Pending &q, bool bad)
+{
+    if (p.state == LagPolicy::ON_FAST) {
+        if (bad) {
+            p.bad_words++;
+            p.backoff_len = 16;
+            p.backoff = p.backoff_len;
+            p.state = LagPolicy::BACKOFF;
         }
-    } else if (c->half_state == X::HALF_PROBE_WAIT && p.probe) {
-        if (reported) {
-            c->half_reports++;
-            c->half_backoff_len = std::min(2 * std::max(c->half_backoff_len, 8), 1024);
-            c->half_backoff = c->half_backoff_len;
-            c->half_state = X::HALF_BACKOFF;
+    } else if (p.state == LagPolicy::PROBE_WAIT && q.probe) {
+        if (bad) {
+            p.bad_words++;
+            p.backoff_len = std::min(2 * std::max(p.backoff_len, 8), p.max_backoff);
+            p.backoff = p.backoff_len;
+            p.state = LagPolicy::BACKOFF;
         } else {
-            c->half_backoff_len = 0;
-            c->half_state = X::HALF_ON_TABLE;
+            p.backoff_len = 0;
+            p.state = LagPolicy::ON_FAST;
         }
     }
-    // (BACKOFF, or a stale non-probe launch: the launches that were in flight when the first report arrived say nothing new)
+    // (BACKOFF, or a stale non-probe launch: the launches that were in flight when the first bad word arrived say nothing new)
 }
 
-bool half_policy(lumahip_ctx *c, uint32_t **flag)
+bool lag_policy_next(LagPolicy &p, uint32_t **flag)
 {
-    using X = lumahip_ctx;
     *flag = nullptr;
-    if (c->half_mode != 1)
-        return c->half_mode == 2;
-    if (!c->h_half_flag) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_half_flag), X::HALF_RING * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-            c->h_half_flag = nullptr;
+    if (!p.h_flag) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&p.h_flag), LagPolicy::RING * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            p.h_flag = nullptr;
             (void)hipGetLastError();
-            return true;   // no feedback channel: behave like mode 2
+            return true;   // no feedback channel: always the fast kernel
         }
-        for (int i = 0; i < X::HALF_RING; i++) {
-            c->h_half_flag[i] = 0;
-            if (hipEventCreateWithFlags(&c->half_ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int i = 0; i < LagPolicy::RING; i++) {
+            p.h_flag[i] = 0;
+            if (hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
-                for (int j = 0; j < i; j++)
-                    (void)hipEventDestroy(c->half_ev[j]);
-                (void)hipHostFree(c->h_half_flag);
-                c->h_half_flag = nullptr;
+                for (int j = 0; j < i; j++) {
+                    (void)hipEventDestroy(p.ev[j]);
+                    p.ev[j] = nullptr;
+                }
+                (void)hipHostFree(p.h_flag);
+                p.h_flag = nullptr;
                 return true;
             }
         }
     }
-    const unsigned long e = c->half_elig++;
-    // the words that are due: table launches issued HALF_LAG or more eligible launches ago, oldest first
-    while (!c->half_pending.empty() && c->half_pending.front().issued_at + X::HALF_LAG <= e) {
-        const X::HalfPending p = c->half_pending.front();
-        c->half_pending.erase(c->half_pending.begin());
-        (void)hipEventSynchronize(c->half_ev[p.slot]);
-        const bool reported = __atomic_load_n(&c->h_half_flag[p.slot], __ATOMIC_RELAXED) != 0;
-        __atomic_store_n(&c->h_half_flag[p.slot], 0u, __ATOMIC_RELAXED);
-        half_report(c, p, reported);
+    const unsigned long e = p.elig++;
+    // the words that are due: fast launches issued LAG or more eligible launches ago, oldest first
+    while (!p.pending.empty() && p.pending.front().issued_at + LagPolicy::LAG <= e) {
+        const LagPolicy::Pending q = p.pending.front();
+        p.pending.erase(p.pending.begin());
+        (void)hipEventSynchronize(p.ev[q.slot]);
+        const bool set = __atomic_load_n(&p.h_flag[q.slot], __ATOMIC_RELAXED) != 0;
+        __atomic_store_n(&p.h_flag[q.slot], 0u, __ATOMIC_RELAXED);
+        lag_policy_word(p, q, set == p.report_is_bad);
     }
     bool probe = false;
-    if (c->half_state == X::HALF_BACKOFF) {
-        if (c->half_backoff > 0) {
-            c->half_backoff--;
-            c->half_backoff_launches++;
+    if (p.state == LagPolicy::BACKOFF) {
+        if (p.backoff > 0) {
+            p.backoff--;
+            p.backoff_launches++;
             return false;
         }
-        c->half_state = X::HALF_PROBE_WAIT;
+        p.state = LagPolicy::PROBE_WAIT;
         probe = true;
-    } else if (c->half_state == X::HALF_PROBE_WAIT) {
-        c->half_backoff_launches++;
+    } else if (p.state == LagPolicy::PROBE_WAIT) {
+        p.backoff_launches++;
         return false;
     }
-    const int slot = (int)(c->half_seq % X::HALF_RING);   // free: at most HALF_LAG - 1 < HALF_RING launches are pending here
-    c->half_pending.push_back({e, slot, probe});
-    *flag = &c->h_half_flag[slot];
+    const int slot = (int)(p.seq++ % LagPolicy::RING);   // free: at most LAG - 1 < RING launches are pending here
+    p.pending.push_back({e, slot, probe});
+    *flag = &p.h_flag[slot];
     return true;
 }
 
-// right behind a table launch that was given a feedback word: the event that says its word is final
-int half_launched(lumahip_ctx *c, hipStream_t s)
+// right behind a fast launch that was given a feedback word: the event that says its word is final
+int lag_policy_launched(lumahip_ctx *c, LagPolicy &p, hipStream_t s)
 {
-    if (c->half_pending.empty())
+    if (p.pending.empty())
         return LUMAHIP_OK;
-    HIPCHK(c, hipEventRecord(c->half_ev[c->half_pending.back().slot], s));
+    HIPCHK(c, hipEventRecord(p.ev[p.pending.back().slot], s));
     return LUMAHIP_OK;
 }
 

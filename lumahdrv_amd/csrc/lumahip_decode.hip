@@ -21,7 +21,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    stage_tables<(MODE == 0 ? STAGE_LUT : 0) | (MODE == 3 ? STAGE_REC : 0)>(smem, a.q);
+    stage_tables<(MODE == 0 ? STAGE_LUT : 0) | ((MODE == 3 || MODE == 7) ? STAGE_REC : 0)>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem);
     const uint32_t *s_rec = reinterpret_cast<const uint32_t *>(smem);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void k_quantize_array(const QArrArgs a)
         int c[1];
         if (!a.lut_channel)
             c[0] = quantize_color(v[0], a.q.maxC);
-        else if constexpr (MODE == 3)
-            quantize_lut<3, 1>(v, c, s_lut, s_rec, a.q);     // any NaN sign
+        else if constexpr (MODE == 3 || MODE == 7)
+            quantize_lut<MODE, 1>(v, c, s_lut, s_rec, a.q);  // any NaN sign
         else if constexpr (MODE == 4)
             quantize_lut<4, 1>(v, c, a.q.lut, a.q.rec, a.q);
         else if constexpr (MODE == 0)
@@ -61,14 +61,40 @@ __global__ __launch_bounds__(256) void k_dequantize_array(const QArrArgs a)
     }
 }
 
+// The per-stream red / blue tables of the YCbCr decode kernels (DecArgs::rb): out[cb * n + y] = blue of (luminance code y,
+// colour code cb), out[plane + cr * n + y] = red, with the complete functions on the device powf (== the host libm's, pow_glibc.hpp)
+struct RbArgs {
+    const float *ytab;   // n entries (+ padding)
+    float *out;
+    int n, nc;           // luminance codes, colour codes
+    float maxC, sc, Lmax;
+};
+
+__global__ __launch_bounds__(256) void k_build_rb(const RbArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(PowfTablesWide)];
+    PowfTablesWide &s_pw = *reinterpret_cast<PowfTablesWide *>(s_raw);
+    stage_powf_tables(&s_pw);
+    __syncthreads();
+    const XformConst k = make_xform_const<CS_YCBCR>(a.sc, a.Lmax, &s_pw);
+    const size_t plane = (size_t)a.n * a.nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * plane; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = i < plane ? i : i - plane;
+        const int cc = (int)(j / a.n), yc = (int)(j - (size_t)cc * a.n);
+        a.out[i] = ycbcr_rb_entry(a.ytab[yc], cc, a.maxC, i < plane ? 1.8814f : 1.4746f, k);
+    }
+}
+
 }  // namespace lh
 
 typedef void (*dec_kernel_t)(const DecArgs);
 
 template <int CS, bool SUB>
-static dec_kernel_t pick_dec2(int vw, bool gl, bool disp, bool yt)
+static dec_kernel_t pick_dec2(int vw, bool gl, bool disp, bool yt, bool rb)
 {
     if constexpr (CS == CS_YCBCR) {
+        if (yt && rb && !gl && !disp)   // + red and blue from the per-stream tables in global memory
+            return vw == 4 ? k_decode<CS, SUB, 4, false, false, true, true> : k_decode<CS, SUB, 2, false, false, true, true>;
         if (yt && !gl && !disp)   // per-stream y table in LDS
             return vw == 4 ? k_decode<CS, SUB, 4, false, false, true> : k_decode<CS, SUB, 2, false, false, true>;
     }
@@ -82,14 +108,14 @@ static dec_kernel_t pick_dec2(int vw, bool gl, bool disp, bool yt)
     return vw == 4 ? k_decode<CS, SUB, 4, false> : k_decode<CS, SUB, 2, false>;
 }
 
-static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp, bool yt)
+static dec_kernel_t pick_dec(int cs, bool sub, int vw, bool gl, bool disp, bool yt, bool rb)
 {
     switch (cs) {
-    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp, yt) : pick_dec2<CS_LUV, false>(vw, gl, disp, yt);
-    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp, yt) : pick_dec2<CS_RGB, false>(vw, gl, disp, yt);
-    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp, yt) : pick_dec2<CS_YCBCR, false>(vw, gl, disp, yt);
-    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp, yt) : pick_dec2<CS_XYZ, false>(vw, gl, disp, yt);
-    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp, yt) : pick_dec2<CS_PACK, false>(vw, gl, disp, yt);
+    case CS_LUV: return sub ? pick_dec2<CS_LUV, true>(vw, gl, disp, yt, rb) : pick_dec2<CS_LUV, false>(vw, gl, disp, yt, rb);
+    case CS_RGB: return sub ? pick_dec2<CS_RGB, true>(vw, gl, disp, yt, rb) : pick_dec2<CS_RGB, false>(vw, gl, disp, yt, rb);
+    case CS_YCBCR: return sub ? pick_dec2<CS_YCBCR, true>(vw, gl, disp, yt, rb) : pick_dec2<CS_YCBCR, false>(vw, gl, disp, yt, rb);
+    case CS_XYZ: return sub ? pick_dec2<CS_XYZ, true>(vw, gl, disp, yt, rb) : pick_dec2<CS_XYZ, false>(vw, gl, disp, yt, rb);
+    case CS_PACK: return sub ? pick_dec2<CS_PACK, true>(vw, gl, disp, yt, rb) : pick_dec2<CS_PACK, false>(vw, gl, disp, yt, rb);
     }
     return nullptr;
 }
@@ -106,6 +132,53 @@ static bool planes_are_separate_buffers(float *const rgb[3], size_t frame_stride
         return (x > y ? x - y : y - x) >= extent;
     };
     return apart(rgb[0], rgb[1]) && apart(rgb[1], rgb[2]) && apart(rgb[0], rgb[2]);
+}
+
+// The device red / blue tables of this call's preScaling (nullptr: not for this stream).  Built by one launch of k_build_rb the
+// first time a preScaling is seen (two tables of 2^(bitdepth + bitdepthC) floats: 8 MiB for the HDR10 recipe, ~20 us), kept per
+// context -- up to two preScalings; launches that read an older copy may still be queued anywhere, so making room waits for the
+// device first.  Only streams whose tables stay within RB_MAX_BYTES (they must live in L2 / MALL to be worth reading).
+static constexpr size_t RB_MAX_BYTES = (size_t)16 << 20;
+
+int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
+{
+    *tab = nullptr;
+    const size_t n = (size_t)c->q.lut_len, nc = (size_t)c->q.maxC + 1;
+    if (c->rb_mode == 0 || !c->q.ytab || 2 * n * nc * sizeof(float) > RB_MAX_BYTES || !(sc == sc))
+        return LUMAHIP_OK;
+    for (auto &t : c->rb_tabs)
+        if (memcmp(&t.sc, &sc, 4) == 0) {
+            t.last_use = ++c->rb_clock;
+            *tab = t.d;
+            return LUMAHIP_OK;
+        }
+    if (c->rb_tabs.size() >= 2) {
+        HIPCHK(c, hipDeviceSynchronize());
+        const size_t old = c->rb_tabs[0].last_use < c->rb_tabs[1].last_use ? 0 : 1;
+        (void)hipFree(c->rb_tabs[old].d);
+        c->rb_tabs.erase(c->rb_tabs.begin() + (long)old);
+    }
+    lumahip_ctx::RbTab t;
+    t.sc = sc;
+    t.last_use = ++c->rb_clock;
+    HIPCHK(c, hipMalloc(&t.d, 2 * n * nc * sizeof(float)));
+    RbArgs a{};
+    a.ytab = c->q.ytab;
+    a.out = t.d;
+    a.n = (int)n;
+    a.nc = (int)nc;
+    a.maxC = c->q.maxC;
+    a.sc = sc;
+    a.Lmax = c->q.Lmax;
+    hipLaunchKernelGGL(k_build_rb, dim3((unsigned)c->num_cu * 8), dim3(256), 0, c->stream, a);
+    // done when this returns, whatever stream or lane the decode launch goes to
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(t.d);
+        return fail(c, LUMAHIP_ERR_HIP, "building the red / blue tables failed");
+    }
+    c->rb_tabs.push_back(t);
+    *tab = t.d;
+    return LUMAHIP_OK;
 }
 
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
@@ -167,7 +240,23 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
             a.aligned = 0;
     }
     a.q.cs = cs_eff;
-    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr, yt);
+    const float *rb = nullptr;
+    uint32_t *rb_flag = nullptr;   // this launch's feedback word (LagPolicy)
+    if (yt && (rc = rb_table_for(c, sc, &rb)))
+        return rc;
+    // mode 1: the kernels with the tables test every wave's codes for locality first (rb_wave_local); on a stream none of whose
+    // waves ever passes, that test and the larger kernel cost 3-4 % for nothing, so launches that report no gathers send the
+    // following ones to the plain kernels for a while
+    if (rb && c->rb_mode == 1 && !lag_policy_next(c->rb_pol, &rb_flag))
+        rb = nullptr;
+    a.rb = rb;
+    a.rb_flag = rb_flag;
+    a.rb_plane = (size_t)c->q.lut_len * ((size_t)c->q.maxC + 1);
+    a.rb_near_y = c->rb_mode == 2 ? -1 : c->rb_near_y;
+    a.rb_near_c = c->rb_near_c;
+    if (rb)
+        c->rb_launches++;
+    dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr, yt, rb != nullptr);
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // few_writers: the 4:2:0 16-bit kernels of the HBM-bound colour spaces (12 of 15 bytes per pixel are writes); 2 when the three
@@ -177,7 +266,10 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     if (few_writers && have_rgb && planes_are_separate_buffers(rgb, frame_stride, nframes, w, h))
         few_writers = 2;
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, few_writers, cs_eff == CS_YCBCR);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, launch_stream(c, lanes), a);
+    hipStream_t s = launch_stream(c, lanes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
+    if (rb_flag && (rc = lag_policy_launched(c, c->rb_pol, s)))
+        return rc;
     HIPCHK(c, hipGetLastError());
     return LUMAHIP_OK;
 }
@@ -206,6 +298,7 @@ int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsi
         case LUT_LITERAL_LDS: kern = k_quantize_array<0>; break;
         case LUT_THRESH_LDS: kern = k_quantize_array<3>; break;
         case LUT_THRESH_GLOBAL: kern = k_quantize_array<4>; break;
+        case LUT_LINKEY_LDS: kern = k_quantize_array<7>; break;
         default: break;
         }
         if (lds > 64 * 1024)
@@ -219,6 +312,24 @@ int array_launch(lumahip_ctx *c, const float *d_in, float *d_out, size_t n, unsi
 }
 
 }  // namespace lhost
+
+extern "C" int lumahip_rb_table_info(lumahip_ctx *c, float sc, int info[4])
+{
+    if (!c || !info)
+        return LUMAHIP_ERR_ARG;
+    if (!c->have_quant)
+        return fail(c, LUMAHIP_ERR_STATE, "quantizer not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    const float *t = nullptr;
+    if (c->q.cs == CS_YCBCR && c->q.ytab && c->lut_in_lds)
+        if (int rc = lhost::rb_table_for(c, sc, &t))
+            return rc;
+    info[0] = t != nullptr;
+    info[1] = t ? (int)(2 * (size_t)c->q.lut_len * ((size_t)c->q.maxC + 1) * sizeof(float)) : 0;
+    info[2] = (int)std::min<unsigned long>(c->rb_launches, 0x7fffffffUL);
+    info[3] = (int)std::min<unsigned long>(c->rb_pol.backoff_launches, 0x7fffffffUL);
+    return LUMAHIP_OK;
+}
 
 extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
                                             const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,

@@ -55,6 +55,8 @@ static enc_kernel_t pick_enc2(int vw, int mode)
         return vw == 4 ? k_encode<CS, SUB, 4, 3> : k_encode<CS, SUB, 2, 3>;
     if (mode == LUT_THRESH_GLOBAL)
         return vw == 4 ? k_encode<CS, SUB, 4, 4> : k_encode<CS, SUB, 2, 4>;
+    if (mode == LUT_LINKEY_LDS)
+        return vw == 4 ? k_encode<CS, SUB, 4, 7> : k_encode<CS, SUB, 2, 7>;
     if (mode == LUT_LITERAL_LDS)
         return k_encode<CS, SUB, 2, 0>;
     return k_encode<CS, SUB, 2, 2>;
@@ -133,7 +135,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     const bool sub = (profile == 0 || profile == 2);
     const int bps = profile > 1 ? 2 : 1;
     const int mode = c->q.mode;
-    const bool fast_search = (mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL);
+    const bool fast_search = (mode == LUT_THRESH_LDS || mode == LUT_THRESH_GLOBAL || mode == LUT_LINKEY_LDS);
     const bool al16 = is_aligned(rgb[0], 16) && is_aligned(rgb[1], 16) && is_aligned(rgb[2], 16);
     int vw = (fast_search && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
     if (!is_aligned(rgb[0], 8) || !is_aligned(rgb[1], 8) || !is_aligned(rgb[2], 8) || (frame_stride % 2) != 0)
@@ -151,7 +153,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     if (ycode && c->half_mode != 0 && lds_bytes(c, true, cs_eff, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
         if ((rc = half_table_for(c, sc, &half)))
             return rc;
-        if (half && !half_policy(c, &half_flag))
+        if (half && c->half_mode == 1 && !lag_policy_next(c->half_pol, &half_flag))   // (mode 2: always, no feedback)
             half = nullptr;
     }
     EncArgs a{};
@@ -159,7 +161,6 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     a.half = half;
     if (half) {
         c->half_launches++;
-        c->half_seq++;
         a.half_flag = half_flag;
     }
     const size_t lds = lds_bytes(c, true, cs_eff, ycode, half != nullptr);
@@ -211,7 +212,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         hipLaunchKernelGGL(k_init_stats, dim3((np + 255) / 256), dim3(256), 0, s, c->d_stats_part, np);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
-    if (half_flag && (rc = half_launched(c, s)))
+    if (half_flag && (rc = lag_policy_launched(c, c->half_pol, s)))
         return rc;
     if (stats)
         hipLaunchKernelGGL(k_fold_stats, dim3((nframes + 63) / 64), dim3(64), 0, s, c->d_stats_part, stats, (int)nframes);
@@ -307,6 +308,7 @@ extern "C" int lumahip_quantize_probe_device(lumahip_ctx *c, uint16_t *out_dev, 
     case LUT_LITERAL_GLOBAL: kern = nonneg ? k_quantize_probe<2, true> : k_quantize_probe<2, false>; break;
     case LUT_THRESH_LDS: kern = nonneg ? k_quantize_probe<3, true> : k_quantize_probe<3, false>; break;
     case LUT_THRESH_GLOBAL: kern = nonneg ? k_quantize_probe<4, true> : k_quantize_probe<4, false>; break;
+    case LUT_LINKEY_LDS: kern = nonneg ? k_quantize_probe<7, true> : k_quantize_probe<7, false>; break;
     }
     if (!kern)
         return fail(c, LUMAHIP_ERR_STATE, "unknown search mode %d", c->q.mode);

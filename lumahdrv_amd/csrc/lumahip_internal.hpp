@@ -37,6 +37,42 @@ static constexpr size_t LUMAHIP_LDS_TABLE_MAX_DEFAULT = 144 * 1024;
 static constexpr size_t LUMAHIP_LDS_PER_WORKGROUP = 160 * 1024;
 static constexpr int LUMAHIP_MAX_LANES = 4;
 
+// Kernel choice from feedback, as a function of the data and of nothing else (lumahip_core.hip lag_policy_*).  Two pairs of
+// kernels compute the same results at different speeds depending on what the stream holds: the YCbCr encode kernels with the
+// half-input table (fast on binary16-valued frames, 1.4 x slower than the per-pixel kernels on others) and the YCbCr decode
+// kernels that may read red / blue from the per-stream tables (fast on pictures, a few per cent slower than the plain ones on
+// unrelated pixels, where no wave ever takes the tables).  Every launch of the data-dependent ("fast") kernel gets its OWN word
+// in a ring of pinned host memory, which the kernel sets to 1 as documented at EncArgs::half_flag / DecArgs::rb_flag, and an
+// event recorded behind it; the host reads launch j's word when it issues the eligible launch LAG later, after that event has
+// completed (normally long ago; at most LAG - 1 launches stay queued behind it, so the device does not run dry).  States:
+//   ON_FAST     fast launches; a BAD word -> BACKOFF for 16 launches (the words of the other launches in flight are dropped);
+//   BACKOFF     plain launches; when the count runs out, ONE fast launch probes -> PROBE_WAIT;
+//   PROBE_WAIT  plain launches until the probe's word is read (LAG launches later): bad -> BACKOFF with the pause doubled (up
+//               to max_backoff), good -> ON_FAST and the pause forgotten.
+// max_backoff weighs a probe's cost against a missed switch: a half-table probe on float data costs 40 % of its launch (1024:
+// 0.04 % of the stream), a red / blue probe on unrelated pixels 3 % while a picture decoded without the tables loses a third (64).
+// `report_is_bad`: whether a set word (true) or a clear one (false) is the bad news.
+struct LagPolicy {
+    static constexpr int LAG = 4, RING = 8;
+    enum { ON_FAST = 0, BACKOFF = 1, PROBE_WAIT = 2 };
+    LagPolicy(bool bad_when_set, int longest_pause) : report_is_bad(bad_when_set), max_backoff(longest_pause) {}
+    bool report_is_bad;
+    int max_backoff;                                 // the pause doubles from 16 up to this many launches
+    uint32_t *h_flag = nullptr;                      // RING words of pinned host memory
+    hipEvent_t ev[RING] = {};
+    struct Pending {
+        unsigned long issued_at;                     // index of the eligible launch this fast launch was
+        int slot;
+        bool probe;                                  // the single fast launch at the end of a back-off
+    };
+    std::vector<Pending> pending;                    // oldest first; at most LAG entries
+    unsigned long elig = 0;                          // eligible launches so far (fast or not)
+    unsigned long seq = 0;                           // fast launches that were given a word
+    int state = ON_FAST;
+    int backoff = 0, backoff_len = 0;                // plain launches left; length of the current back-off
+    unsigned long backoff_launches = 0, bad_words = 0;
+};
+
 struct lumahip_copy_pool;                                   // lumahip_host.hip: worker threads of the staging copies
 void lumahip_copy_pool_destroy(lumahip_copy_pool *p);
 
@@ -52,6 +88,8 @@ struct lumahip_ctx {
     unsigned bitdepth = 0, bitdepthC = 0;
     lh::QuantDev q{};
     std::shared_ptr<const lh::ThreshIndex> tix;  // encode-side search index, built on first use (ensure_search_index)
+    std::shared_ptr<const lh::LinIndex> lix;     // value-keyed records, when the float-bit ones miss LDS and these fit (PTF_LINEAR)
+    bool use_lin_index = true;                   // lumahip_tune("lin_index", 0): never (A/B, tests)
     bool index_ready = false;
     // YCbCr only: records of the composite luma -> code function (encode), the per-stream y table (decode); host_lut.cpp
     std::shared_ptr<const lh::ThreshIndex> tix_y;
@@ -69,25 +107,20 @@ struct lumahip_ctx {
     std::vector<HalfTab> half_tabs;
     unsigned long half_clock = 0;
     int half_mode = 1;            // lumahip_tune("half_table"): 0 = never, 1 = while the stream looks like binary16 data (half_policy), 2 = always
-    // Feedback of the half-input kernels (EncArgs::half_flag; lumahip_core.hip half_policy): every table launch has its OWN word
-    // in a ring of pinned host memory and an event recorded behind it; the host reads launch j's word when it issues the
-    // eligible launch HALF_LAG later, after that event has completed -- so which kernel a launch takes is a function of the
-    // stream's data and of nothing else (no timing).
-    static constexpr int HALF_LAG = 4, HALF_RING = 8;
-    uint32_t *h_half_flag = nullptr;                 // HALF_RING words
-    hipEvent_t half_ev[HALF_RING] = {};
-    struct HalfPending {
-        unsigned long issued_at;                     // index of the eligible launch this table launch was
-        int slot;
-        bool probe;                                  // the single table launch at the end of a back-off
+    LagPolicy half_pol{true, 1024};     // which kernel an eligible YCbCr encode launch takes (half_mode 1): a report = "these are not halves"
+    unsigned long half_launches = 0;
+    // YCbCr decode: device copies of the per-stream red / blue tables (lumahip_decode.hip rb_table_for), one per preScaling seen
+    struct RbTab {
+        float sc = 0.0f;
+        float *d = nullptr;
+        unsigned long last_use = 0;
     };
-    std::vector<HalfPending> half_pending;           // oldest first; at most HALF_LAG entries
-    unsigned long half_elig = 0;                     // eligible launches so far (table or not)
-    uint32_t half_seq = 0;                           // table launches so far
-    enum { HALF_ON_TABLE = 0, HALF_BACKOFF = 1, HALF_PROBE_WAIT = 2 };
-    int half_state = HALF_ON_TABLE;
-    int half_backoff = 0, half_backoff_len = 0;      // launches left on the per-pixel kernels; length of the current back-off
-    unsigned long half_launches = 0, half_backoff_launches = 0, half_reports = 0;
+    std::vector<RbTab> rb_tabs;
+    unsigned long rb_clock = 0, rb_launches = 0;
+    LagPolicy rb_pol{false, 64};      // which kernel an eligible YCbCr decode launch takes (rb_mode 1): NO report = "no wave found its codes local"
+    int rb_mode = 1;              // lumahip_tune("ycbcr_rb_tables"): 0 = six powf per pixel (rounds 3-4), 1 = red / blue from the tables where a
+                                  // wave's codes are close to each other (luma_kernels.hpp rb_wave_near), 2 = from the tables always
+    int rb_near_y = 64, rb_near_c = 24;    // lumahip_tune("rb_near_y" / "rb_near_c"): the closeness bounds of mode 1 (luma_kernels.hpp rb_wave_local)
     bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
     std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer
     float *d_lut = nullptr;
@@ -239,11 +272,13 @@ int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int fe
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)
 bool ycbcr_composite_ready(const lumahip_ctx *c);   // encode: the composite luma -> code records exist and fit LDS
 int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the device half-input table of (sc, the quantizer's Lmax), or nullptr: none
-// this eligible launch: the half-input kernel (true) or the per-pixel one.  On true, *flag is the launch's feedback word (nullptr:
-// none wanted) and the caller calls half_launched(c, stream) right behind the kernel launch.
-bool half_policy(lumahip_ctx *c, uint32_t **flag);
-int half_launched(lumahip_ctx *c, hipStream_t s);
-void half_policy_reset(lumahip_ctx *c);
+// this eligible launch: the data-dependent ("fast") kernel (true) or the plain one.  On true, *flag is the launch's feedback
+// word (nullptr when the feedback ring could not be set up: the policy then always answers true) and the caller calls
+// lag_policy_launched(c, p, stream) right behind the kernel launch.
+bool lag_policy_next(LagPolicy &p, uint32_t **flag);
+int lag_policy_launched(lumahip_ctx *c, LagPolicy &p, hipStream_t s);
+void lag_policy_reset(LagPolicy &p);      // a new stream: waits for the launches in flight, clears their words, state ON_FAST
+void lag_policy_destroy(LagPolicy &p);
 void numa_resolve(lumahip_ctx *c);                                 // fills numa_node / numa_cpus once (cheap afterwards)
 int check_geom(lumahip_ctx *c, unsigned w, unsigned h, int profile, int cs_eff);
 bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nframes);

@@ -20,6 +20,8 @@ size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode,
             b += lut_b;
         if (q.mode == LUT_THRESH_LDS)
             b += ((size_t)q.nbuckets * 4 + 15) & ~(size_t)15;
+        if (q.mode == LUT_LINKEY_LDS)
+            b += ((size_t)q.nbuckets * 8 + 15) & ~(size_t)15;
     } else if (c->lut_in_lds) {
         b += lut_b;
         if (cs_eff == CS_LUV)

@@ -18,7 +18,9 @@ enum LutMode : int {
     LUT_LITERAL_LDS = 0,    // reference bisection, table staged in LDS
     LUT_LITERAL_GLOBAL = 2, // reference bisection on the table in global memory (bitdepth > 12)
     LUT_THRESH_LDS = 3,     // threshold records staged in LDS: ONE 4-byte LDS read per value
-    LUT_THRESH_GLOBAL = 4   // threshold records in global memory / L2 (record table too large for LDS)
+    LUT_THRESH_GLOBAL = 4,  // threshold records in global memory / L2 (record table too large for LDS)
+    // (5, 6: the YCbCr composite records / + the half-input table; kernel-side numbers only, luma_kernels.hpp)
+    LUT_LINKEY_LDS = 7      // value-keyed records staged in LDS (evenly spaced tables: PTF_LINEAR), see LinIndex below
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -51,6 +53,30 @@ struct ThreshIndex {
     int nbuckets = 0;
     std::vector<uint32_t> rec;
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Value-keyed records, for tables whose entries are (about) evenly spaced in VALUE -- PTF_LINEAR,
+// src/luma_quantizer.cpp:200-203: map[i] = Lmax * i / maxVal.  Their thresholds are evenly spaced too, so a key made of
+// float bits needs as many mantissa bits at EVERY exponent as the top exponent does (LINEAR-12: 12 bits x 14 exponents =
+// 57 000 buckets, 229 KiB: not in LDS).  Keyed by value there are about maxVal + 2 buckets:
+//     key(v) = cvt_u32(min(v * kscale, nbuckets - 1))        (one fp32 product, rounded; NaN -> top bucket through the min;
+//                                                             the conversion truncates and sends negatives to 0)
+//     rec[key] = {P, start}:  code(v) = start + ((int)bits(v) > (int)P),   P = bits(T) - 1
+// key() is non-decreasing in v (rounding is monotone), so a bucket is a contiguous range of floats, every threshold with
+// a smaller key than v's is <= v and every one with a larger key is > v: `start` = c0 + the thresholds in earlier buckets,
+// P = the bit pattern just below the one threshold T inside the bucket (0x7fffffff: none; the SIGNED comparison is then
+// false for every float -- the all-ones NaN included, which is why the record holds T - 1 and the test is strict -- and it is
+// false for every negative v in bucket 0, whose patterns are negative integers).  kscale is chosen from the
+// smallest gap between two thresholds so that no bucket holds two; the top bucket (everything beyond the last threshold,
+// +inf, every NaN) has start maxVal.  8 bytes per bucket: LINEAR-12 32 KiB, LINEAR-14 128 KiB.
+struct LinIndex {
+    bool ok = false;
+    float kscale = 0.0f;
+    int nbuckets = 0;
+    std::vector<uint32_t> rec;   // 2 words per bucket: P = bits(T) - 1 (0x7fffffff: no threshold), start
+};
+int lin_lookup_host(const LinIndex &ix, float v);   // device-equivalent evaluation
+LinIndex build_lin_index(const float *lut, int n, int max_buckets);
 
 // the reference's loop, literally (src/luma_quantizer.cpp:222-235)
 int quantize_literal_host(float v, const float *lut, int maxVal);

@@ -1,6 +1,7 @@
 """Exhaustive statements that only a GPU makes affordable.
 
-1. The luminance search the kernels ship with -- threshold records, lut_index.hpp / quantize_thresh -- returns the
+1. The luminance search the kernels ship with -- threshold records keyed by float bits (lut_index.hpp / quantize_thresh) and,
+   for evenly spaced tables (PTF_LINEAR from 12 bits), keyed by value (LinIndex / quantize_linkey) -- returns the
    same code as the reference's bisection + nearest-of-two (src/luma_quantizer.cpp:222-235) for EVERY fp32 bit
    pattern (all 2^32: zeros, denormals, negatives, +-inf, every NaN payload), for each shipped transfer function,
    through three different instantiations:
@@ -23,7 +24,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12), (1, 13)]   # (1, 13): 136 KiB of records, one workgroup per CU
+# (1, 13): 136 KiB of records, one workgroup per CU; (4, 12) / (4, 14): PTF_LINEAR, value-keyed records (search mode 7: 32 / 128 KiB)
+TABLES = [(1, 11), (1, 10), (2, 12), (4, 12), (0, 11), (3, 12), (1, 8), (1, 12), (1, 13), (4, 14)]
 
 
 def _pair(L, ptf, bits, cs):
@@ -31,7 +33,7 @@ def _pair(L, ptf, bits, cs):
     lut = L.build_lut(ptf, bits, 1e4, 0.005)
     fast = L.Context(0)
     fast.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
-    assert fast.quantizer_info()["mode"] in (3, 4)
+    assert fast.quantizer_info()["mode"] == (7 if ptf == 4 and bits >= 12 else 3)
     lit = L.Context(0)
     lit.tune("force_literal", 1)
     lit.set_quantizer(ptf, bits, cs, 8, 1e4, 0.005, lut)
@@ -81,9 +83,9 @@ def test_record_search_equals_bisection_for_every_float(oracle_mod, ptf, bits):
     lit.set_stream(None)
 
 
-@pytest.mark.parametrize("ptf,bits", [(1, 11), (2, 12), (1, 12), (1, 8)])
+@pytest.mark.parametrize("ptf,bits", [(1, 11), (2, 12), (1, 12), (1, 8), (4, 12)])
 def test_encode_kernel_search_equals_bisection_for_every_float(oracle_mod, ptf, bits):
-    """(b): the fused encode kernel, k_encode<CS_RGB, 4:4:4, VW=4, records>.  Frames of 8192 x 4096 pixels whose three
+    """(b): the fused encode kernel, k_encode<CS_RGB, 4:4:4, VW=4, records> (LINEAR-12: value-keyed records, LM = 7).  Frames of 8192 x 4096 pixels whose three
     planes hold consecutive bit patterns (3 x 2^25 per frame, 43 frames cover 2^32 with wrap-around); profile 3
     (16-bit 4:4:4) writes one code per input float.  PQ-11 / LOG-12 are BASELINE configs 1 and 4's tables; PQ-8 goes
     through profile 1 (8-bit samples)."""

@@ -155,7 +155,7 @@ def test_pairs_without_a_table_and_the_table_cache(oracle_mod):
         assert np.array_equal(got[p], exp[p]), p
 
 
-def _half_policy_model(kinds, lag=4):
+def _half_policy_model(kinds, lag=4, longest=1024):
     """lumahip_core.hip half_policy restated: kinds[i] = True when eligible launch i holds full-precision floats (a table launch on
     it reports).  Returns, per launch, (table launches so far, back-off launches so far) AFTER it was issued."""
     ON, BACKOFF, PROBE_WAIT = 0, 1, 2
@@ -168,7 +168,7 @@ def _half_policy_model(kinds, lag=4):
                 left = length
             elif state == PROBE_WAIT and probe:
                 if reported:
-                    length = min(2 * max(length, 8), 1024)
+                    length = min(2 * max(length, 8), longest)
                     state, left = BACKOFF, length
                 else:
                     state, length = ON, 0

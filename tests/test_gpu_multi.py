@@ -192,5 +192,12 @@ def test_bench_config3_encode_is_hbm_bound():
     assert fi["value"] > 0 and fi["roofline"]["bound"] == "valu" and 0 < fi["hbm_frac"] < 1
     n = fi["table_launches"] + fi["backoff_launches"]
     assert n >= 8 and _half_policy_model([True] * n)[-1] == (fi["table_launches"], fi["backoff_launches"]), fi
+    # decode of a picture-like stream (the red / blue tables are read) next to the synthetic stream's (they are not: its launches
+    # report no local wave and the policy -- the same model, pause capped at 64 -- sends the rest to the plain kernels)
+    dc = r["decode_coherent"]
+    assert dc["value"] > 0 and dc["backoff_launches"] == 0 and dc["table_launches"] >= 8 and dc["rb_table_bytes"] == 8 << 20, dc
+    dp = r["decode_random_rb_policy"]
+    n = dp["table_launches"] + dp["backoff_launches"]
+    assert _half_policy_model([True] * n, longest=64)[-1] == (dp["table_launches"], dp["backoff_launches"]), dp
     mi = r["mixed_inputs_1e-3"]
     assert mi["value"] > 0 and mi["backoff_launches"] == 0 and mi["table_launches"] >= 8, mi   # 1e-3 of the pixels: stays on the table

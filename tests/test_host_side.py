@@ -347,6 +347,47 @@ def test_threshold_records_on_random_monotone_tables(L, oracle_mod):
     assert accepted >= 40 and accepted + refused == 60
 
 
+def test_value_keyed_records_of_evenly_spaced_tables(L, oracle_mod):
+    """PTF_LINEAR tables (src/luma_quantizer.cpp:200-203) and other evenly spaced ones: their float-bit records miss LDS from 12
+    bits (229 KiB), the VALUE-keyed records (lut_index.hpp LinIndex; search mode 7) hold about one bucket per code.  Wherever
+    the builder accepts a table its records must equal the oracle's literal search around every table entry and midpoint, on a
+    random sample of values and of bit patterns, and on the special values; PQ / LOG tables (thresholds crowd near zero) and
+    tables with duplicates must be refused."""
+    from lumahdrv_amd import capi
+    o = oracle_mod
+    rng = np.random.default_rng(7)
+    cases = [(capi.build_lut(capi.PTF_LINEAR, b, mx, 0.005), b) for b, mx in ((12, 1e4), (8, 1e4), (10, 1000.0), (13, 1e4), (14, 1e4), (11, 0.37), (4, 3e38))]
+    jit = (np.arange(4096) * 2.5 + rng.uniform(-0.3, 0.3, 4096)).astype(np.float32)          # evenly spaced with jitter
+    jit[0] = 0.0
+    cases.append((np.sort(jit), 12))
+    for m, bits in cases:
+        ix = capi.lin_index(m)
+        # PTF_LINEAR: one bucket per code (+ 0.2 % + the two ends); the jittered table: its smallest gap sets the bucket width
+        assert ix["ok"] and ix["nbuckets"] <= (1.5 if m is cases[-1][0] else 1.02) * m.size + 8, (bits, ix["nbuckets"])
+        orc = o.Oracle(o.PTF_PQ, bits, o.CS_RGB, 8, 1e4, 0.005)
+        orc.overwrite_mapping(m)
+        mids = ((m[:-1].astype(np.float64) + m[1:]) / 2).astype(np.float32)
+        v = np.concatenate([m, np.nextafter(m, np.float32(np.inf)), np.nextafter(m, np.float32(-np.inf)), mids,
+                            np.nextafter(mids, np.float32(np.inf)), np.nextafter(mids, np.float32(-np.inf)),
+                            rng.uniform(-0.01 * float(m[-1]), min(1.2 * float(m[-1]), 3.4e38), 20000).astype(np.float32),
+                            rng.integers(0, 1 << 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                            np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, -np.nan, 1e-45, -1e-45, 3.4e38, -3.4e38], dtype=np.float32),
+                            np.array([0x7f800001, 0xff800001, 0x7fffffff, 0xffffffff], dtype=np.uint32).view(np.float32)])
+        v = np.concatenate([v, np.ones((-v.size) % 2, dtype=np.float32)])
+        got = capi.lin_lookup(ix, v)
+        frame = np.stack([v.reshape(2, -1)] * 3).copy()
+        with np.errstate(all="ignore"):
+            planes, _, _ = orc.encode(frame, 1.0, 3 if bits > 8 else 1)
+        w = frame.shape[2]
+        exp = (planes[0].view("<u2")[:, :w] if bits > 8 else planes[0][:, :w]).reshape(-1).astype(np.int64)
+        assert np.array_equal(got & (0xFFFF if bits > 8 else 0xFF), exp), bits
+    for ptf, bits in ((capi.PTF_PQ, 11), (capi.PTF_LOG, 12), (capi.PTF_PQ, 8)):
+        assert not capi.lin_index(capi.build_lut(ptf, bits, 1e4, 0.005))["ok"]
+    dup = capi.build_lut(capi.PTF_LINEAR, 10, 1e4, 0.005)
+    dup[500] = dup[499] = dup[498]
+    assert not capi.lin_index(dup)["ok"]
+
+
 def test_ycbcr_stream_tables_equal_the_reference_arithmetic(L, oracle_mod):
     """The two per-stream tables of the YCbCr kernels, built on the host with libm (host_lut.cpp): (1) the composite
     "t = 219 y + 16 -> luminance code" threshold records against the oracle's PQdec(t / 255) + literal search

@@ -21,11 +21,16 @@ def main():
     rows = []
     cases = [(L.PTF_PQ, 11, cs, 8, None) for cs in (L.CS_LUV, L.CS_RGB, L.CS_YCBCR, L.CS_XYZ)]
     cases += [(L.PTF_LOG, 12, L.CS_LUV, 8, None), (L.PTF_PSI, 11, L.CS_LUV, 8, None), (L.PTF_PQ, 11, L.CS_LUV, 8, "literal"),
-              (L.PTF_PQ, 13, L.CS_LUV, 8, None)]
+              (L.PTF_PQ, 13, L.CS_LUV, 8, None),
+              # PTF_LINEAR: value-keyed records in LDS (search mode 7) against the float-bit records in global memory (mode 4)
+              (L.PTF_LINEAR, 12, L.CS_LUV, 8, None), (L.PTF_LINEAR, 12, L.CS_LUV, 8, "no_lin_index"),
+              (L.PTF_LINEAR, 14, L.CS_LUV, 8, None), (L.PTF_LINEAR, 14, L.CS_LUV, 8, "no_lin_index"), (L.PTF_LINEAR, 12, L.CS_RGB, 8, None)]
     for ptf, bits, cs, bitsC, force in cases:
         ctx = L.Context(0)
-        if force:
+        if force == "literal":
             ctx.tune("force_literal", 1)
+        if force == "no_lin_index":
+            ctx.tune("lin_index", 0)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_quantizer(ptf, bits, cs, bitsC, 1e4, 0.005, L.build_lut(ptf, bits))
         info = ctx.quantizer_info()
