@@ -1061,7 +1061,7 @@ def main():
         if rank == 0:
             res["roofline"] = r["roofline"]
             res["decode_roofline"] = r["decode_roofline"]
-            for k in ("float_inputs", "mixed_inputs_1e-3"):     # (--workload pq10_ycbcr: the legs other_workloads.pq10_ycbcr_4k carries by default)
+            for k in ("float_inputs", "mixed_inputs_1e-3", "decode_coherent", "decode_random_rb_policy"):     # (--workload pq10_ycbcr: the legs other_workloads.pq10_ycbcr_4k carries by default)
                 if k in r:
                     res[k] = r[k]
         if pool is not None and args.workload == "pq11_luv" and not args.no_placement_off:
