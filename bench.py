@@ -372,8 +372,8 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
         # the three-buffer layout the legs above write: the same decode launches into packed frames, a ring of PACKED_RING
         # batches (>> the 256 MB MALL), once in chunks of the pool (the fastest float chunks left) and once in a plain allocation.
         pk = {}
-        # "pool_rotating": batch b's packed frames in a chunk of region group b mod 3, so that the launches in flight on the
-        # two lanes write different groups (profiles/r03_layout_lab.txt found 0.75 for that arrangement)
+        # "pool_rotating": batch b's packed frames in the b-th chunk the pool hands out in its ROTATING mode (region groups 0, 1,
+        # 2, 0, ...), so that the launches in flight on the two lanes write different groups (profiles/r03_layout_lab.txt: 0.75)
         for how in ("pool_placed", "pool_rotating", "plain"):
             ring = rot = None
             if how == "pool_placed":
@@ -384,8 +384,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             elif how == "pool_rotating":
                 if min(len(g) for g in pool.striped) < PACKED_RING // 3:
                     continue
-                rot = pool.take_striped(PACKED_RING // 3)
-                ring = [rot[k % 3][k // 3] for k in range(PACKED_RING)]
+                rot = ring = pool.take_rotating(PACKED_RING)       # lumahip_pool_alloc(LUMAHIP_POOL_ROTATING): no group arithmetic here
             plain = torch.empty(PACKED_RING * B * n3, dtype=torch.float32, device=dev) if how == "plain" else None
             nring = len(ring) if ring is not None else PACKED_RING
 
@@ -402,7 +401,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                        "kernel_ms": round(tp["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(tpo["dev_ms_median"] / K, 4),
                        "frac_ordered": fr(tpo["dev_ms_median"] / K), "frac_overlapped": fr(tp["dev_ms_median"] / K), "batches_in_ring": nring}
             if rot is not None:
-                pool.give_back([], [], [], rot)
+                pool.give_back_rotating(rot)
             elif ring is not None:
                 pool.give_back(ring, [], [])
             del plain
@@ -1055,6 +1054,9 @@ def main():
             "decode_mpix_s": r["decode_mpix_s"], "decode_output_layout": r["decode_output_layout"],
             "roundtrip_mpix_s": r["roundtrip_mpix_s"],
             "decode_packed_layout": r.get("decode_packed_layout"),
+            # the reference's own decode layout (LumaDecoder::decode() returns a packed LumaFrame) at its best placement: output chunks
+            # taken from the pool in its ROTATING mode, two launches in flight
+            "decode_packed_mpix_s": ((r.get("decode_packed_layout") or {}).get("pool_rotating") or {}).get("value"),
             "kernel_source_sha": sha,
             "placement": dict({"mode": args.placement}, **(pool.stats if pool is not None else {})),
         }

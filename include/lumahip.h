@@ -35,7 +35,22 @@
 extern "C" {
 #endif
 
-#define LUMAHIP_ABI_VERSION 3   /* 3: round-4 additions (value_host scalar forms, half-input table, NUMA, multi transport); nothing removed or changed */
+/* ABI history.  The BINARY interface has only ever grown: every symbol of an earlier version is still exported with the same
+ * signature, so a program linked against version 2 runs against this library.
+ *   4 (round 5): additions -- lumahip_rb_table_info, lumahip_lin_index_host, LUMAHIP_POOL_ROTATING, the lumahip_tune keys
+ *     "ycbcr_rb_tables" / "rb_near_y" / "rb_near_c" / "lin_index"; lumahip_quantizer_info may answer search mode 7.  Behaviour:
+ *     the half-input table's kernel choice is now a function of the stream's data only (feedback read four eligible launches
+ *     later, after the launch's completion event) -- launch counts of lumahip_half_table_info on a float stream differ from
+ *     version 3's, results never did; YCbCr decode launches may read the red / blue tables (same results).
+ *   3 (round 4): additions (value_host scalar forms, half-input table, NUMA, multi transport).  SOURCE-level break: about ten
+ *     declarations that version 2's header showed unconditionally are test / measurement hooks and moved into the
+ *     `#ifdef LUMAHIP_EXPERIMENTAL` section at the end (lumahip_thresh_index_host, lumahip_ycbcr_*_host,
+ *     lumahip_synth_frames_device, lumahip_time_launches, the traffic probes, ...): C / C++ callers that use them define
+ *     LUMAHIP_EXPERIMENTAL before including this header; the symbols themselves are unchanged.  Behaviour changes of version 3:
+ *     lumahip_time_launches returns LUMAHIP_ERR_STATE inside an unordered section, the default of lumahip_tune("copy_threads")
+ *     went from 3 to 5, and lumahip_multi_* with every shard on one device takes the table from the host instead of RCCL
+ *     (lumahip_multi_set_transport(m, 1) restores the broadcast). */
+#define LUMAHIP_ABI_VERSION 4
 
 enum lumahip_status {
     LUMAHIP_OK = 0,
@@ -361,7 +376,8 @@ int lumahip_numa_plan_host(const char *sysfs_root, const char *pci_bus_id, const
  * n_striped further chunks from EACH of the first three groups, and gives the rest back to the driver.  Nothing here touches results:
  * the pool decides addresses only.  `ctx` must have a quantizer set and is used for the probes during creation only. */
 typedef struct lumahip_pool lumahip_pool;
-enum lumahip_pool_kind { LUMAHIP_POOL_FLOAT = 0, LUMAHIP_POOL_Y = 1, LUMAHIP_POOL_UV = 2, LUMAHIP_POOL_STRIPED = 3 };
+enum lumahip_pool_kind { LUMAHIP_POOL_FLOAT = 0, LUMAHIP_POOL_Y = 1, LUMAHIP_POOL_UV = 2, LUMAHIP_POOL_STRIPED = 3,
+                         LUMAHIP_POOL_ROTATING = 4 /* an allocation mode over the STRIPED chunks, see lumahip_pool_alloc */ };
 typedef struct lumahip_pool_config {
     size_t chunk_bytes;      /* 0 = 2 GiB */
     int n_float, n_y, n_uv;  /* chunks wanted of each kind */
@@ -373,7 +389,13 @@ typedef struct lumahip_pool_config {
 int lumahip_pool_create(lumahip_ctx *ctx, const lumahip_pool_config *cfg, lumahip_pool **out);
 void lumahip_pool_destroy(lumahip_pool *pool);   /* frees every chunk, handed out or not */
 /* One whole chunk of `kind` (fastest first).  group: -1 = any; for LUMAHIP_POOL_STRIPED the region group (0, 1, 2) the chunk
- * must come from.  LUMAHIP_ERR_STATE when none is left. */
+ * must come from.  LUMAHIP_ERR_STATE when none is left.
+ * LUMAHIP_POOL_ROTATING: for PACKED decoded frames (the reference's LumaFrame layout, include/luma/luma_frame.h:84-87, what
+ * lumahip_decode_frames_device writes).  One decode launch writes one batch, a batch of packed frames lives in one chunk, i.e. in
+ * ONE region group -- 0.69 of the roofline wherever the chunk is; what helps is two launches in flight that write DIFFERENT
+ * groups (an unordered section).  Consecutive ROTATING allocations hand out the STRIPED chunks of groups 0, 1, 2, 0, ... (group >=
+ * 0 restarts the walk there; an exhausted group is skipped), so "allocate the output buffer of every batch in stream order" is
+ * all a caller has to do: 0.69 -> 0.75 (bench.py decode_packed_layout.pool_rotating). */
 int lumahip_pool_alloc(lumahip_pool *pool, int kind, int group, void **chunk_dev);
 int lumahip_pool_release(lumahip_pool *pool, void *chunk_dev);
 /* number of chunks of `kind` (and group, -1 = any) still available */

@@ -206,7 +206,7 @@ class PoolConfig(C.Structure):
                 ("keep_free_bytes", C.c_size_t), ("max_chunks", C.c_int), ("probe_iters", C.c_int)]
 
 
-POOL_FLOAT, POOL_Y, POOL_UV, POOL_STRIPED = range(4)
+POOL_FLOAT, POOL_Y, POOL_UV, POOL_STRIPED, POOL_ROTATING = range(5)
 
 
 def shard_range(nframes: int, shard: int, nshards: int) -> range:

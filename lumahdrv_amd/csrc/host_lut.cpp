@@ -17,6 +17,7 @@
 #define LUMAHIP_EXPERIMENTAL   /* the library defines what the experimental section of the header declares */
 #include "../../include/lumahip.h"
 #include "host_lut.hpp"
+#include "pow_glibc.hpp"
 #include "lut_index.hpp"
 
 namespace {
@@ -155,10 +156,24 @@ bool ycbcr_half_table_host(float sc, float Lmax, float *out)
             x = INFINITY;  // i == 0x7C00, m == 0
         else
             x = ldexpf((float)(m | 0x400u), (int)e - 25);
-        const float v = pq_encode_host(Lmax, std::max(x * sc, 1e-10f));
+        const float arg = std::max(x * sc, 1e-10f);
+        const float v = pq_encode_host(Lmax, arg);
         out[i] = v;
         if (!(v != v) && !(v >= 7e-7f && v <= 2.0f))
             return false;
+        // A pixel that misses the table in the same launch goes through the kernels' restatement of glibc 2.35's powf
+        // (pow_glibc.hpp); what the table holds came from THIS host's libm.  On the hosts this was written for the two are the
+        // same function bit for bit (tools/verify_powf.cpp); on a host whose libm differs (musl, another glibc) they would
+        // not be, and a plane would then depend on whether a pixel's inputs happen to be halves.  So every entry is checked
+        // against the restatement evaluated on the host, and the table is refused -- the kernels evaluate every pixel -- on
+        // the first difference.
+        {
+            const float m = 78.8438, n = 0.1593, c1 = 0.8359, c2 = 18.8516, c3 = 18.6875;
+            const float Lp = powf_glibc(arg / Lmax, n, kPowfTablesHost);
+            const float r = powf_glibc((c1 + c2 * Lp) / (1 + c3 * Lp), m, kPowfTablesHost);
+            if (std::memcmp(&r, &v, sizeof r) != 0 && !(r != r && v != v))
+                return false;
+        }
     }
     return true;
 }

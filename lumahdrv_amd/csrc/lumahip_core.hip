@@ -779,10 +779,17 @@ void numa_resolve(lumahip_ctx *c)
     c->numa_cpus.clear();
     if (!c->numa_mode)
         return;
-    FILE *two = fopen("/sys/devices/system/node/node1/cpulist", "r");   // a second node exists?
-    if (!two)
-        return;
-    fclose(two);
+    // more than one memory node online?  (node numbers can be sparse -- "0,2" -- so the list is read, not node1 probed)
+    {
+        char buf[256] = {0};
+        FILE *on = fopen("/sys/devices/system/node/online", "r");
+        if (!on)
+            return;
+        const bool got = fgets(buf, sizeof buf, on) != nullptr;
+        fclose(on);
+        if (!got || (!strchr(buf, ',') && !strchr(buf, '-')))
+            return;   // "0": one node
+    }
     int node = c->numa_force_node;
     if (node < 0) {
         int v = -1;

@@ -246,7 +246,18 @@ static int stage_alloc(lumahip_ctx *c, lumahip_ctx::Stage &st, size_t bytes = XF
         bool placed = false;
         if (c->numa_node >= 0 && c->numa_mode != 3 && numa_prefer_node(c->numa_node)) {
             placed = hipHostMalloc((void **)&st.h, bytes, hipHostMallocNumaUser) == hipSuccess;
-            (void)numa_prefer_node(-1);
+            if (!numa_prefer_node(-1)) {
+                // the caller's memory policy could not be put back: its later allocations would silently prefer the GPU's node.
+                // Say so, and stop placing rings for this context (the rings already made stay where they are)
+                c->numa_mode = 0;
+                c->numa_node = -1;
+                (void)fail(c, LUMAHIP_ERR_STATE, "set_mempolicy could not restore the calling thread's memory policy after placing a "
+                                                 "staging ring; NUMA placement is off for this context from here on");
+                if (placed)
+                    (void)hipHostFree(st.h);
+                st.h = nullptr;
+                return LUMAHIP_ERR_STATE;
+            }
             if (!placed) {
                 st.h = nullptr;
                 (void)hipGetLastError();

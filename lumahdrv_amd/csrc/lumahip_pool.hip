@@ -135,6 +135,7 @@ struct lumahip_pool {
     size_t chunk_bytes = 0;
     std::vector<Chunk> chunks;  // kept chunks only, in hand-out order per kind
     std::string json;
+    unsigned rot_next = 0;      // LUMAHIP_POOL_ROTATING: the group the next chunk should come from
 };
 
 extern "C" void lumahip_pool_destroy(lumahip_pool *pool)
@@ -376,6 +377,23 @@ extern "C" int lumahip_pool_alloc(lumahip_pool *pool, int kind, int group, void 
     if (!pool || !chunk)
         return LUMAHIP_ERR_ARG;
     *chunk = nullptr;
+    if (kind == LUMAHIP_POOL_ROTATING) {
+        // consecutive allocations walk the region groups 0, 1, 2, 0, ... (the chunks kept for LUMAHIP_POOL_STRIPED): a caller that
+        // gives consecutive batches of PACKED frames consecutive allocations has launches in flight that write different groups
+        // without knowing about groups.  `group` >= 0 restarts the walk at that group.  A group that has run out is skipped.
+        if (group >= 0)
+            pool->rot_next = (unsigned)group;
+        for (int tries = 0; tries < 3; tries++) {
+            const int g = (int)(pool->rot_next++ % 3u);
+            for (Chunk &c : pool->chunks)
+                if (!c.out && c.kind == LUMAHIP_POOL_STRIPED && c.group == g) {
+                    c.out = true;
+                    *chunk = c.p;
+                    return LUMAHIP_OK;
+                }
+        }
+        return LUMAHIP_ERR_STATE;
+    }
     for (Chunk &c : pool->chunks)
         if (!c.out && c.kind == kind && (group < 0 || c.group == group)) {
             c.out = true;
@@ -402,6 +420,10 @@ extern "C" int lumahip_pool_available(const lumahip_pool *pool, int kind, int gr
     if (!pool)
         return 0;
     int k = 0;
+    if (kind == LUMAHIP_POOL_ROTATING) {   // (they are the striped chunks; `group` does not restrict what a rotating allocation may fall back to)
+        kind = LUMAHIP_POOL_STRIPED;
+        group = -1;
+    }
     for (const Chunk &c : pool->chunks)
         if (!c.out && c.kind == kind && (group < 0 || c.group == group))
             k++;

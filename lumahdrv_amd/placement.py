@@ -58,19 +58,21 @@ class HbmChunkPool:
         self.stats = self.pool.stats()
         self._ptr = {}
 
-        def take_all(kind, group=-1):
-            out = []
-            while self.pool.available(kind, group) > 0:
-                p = self.pool.alloc(kind, group)
-                t = as_tensor(p, CHUNK_BYTES, dev)
-                self._ptr[t.data_ptr()] = p
-                out.append(t)
-            return out
+        self.float = self._take_all(capi.POOL_FLOAT)
+        self.y = self._take_all(capi.POOL_Y)
+        self.uv = self._take_all(capi.POOL_UV)
+        self.striped = [self._take_all(capi.POOL_STRIPED, g) for g in range(3)]
 
-        self.float = take_all(capi.POOL_FLOAT)
-        self.y = take_all(capi.POOL_Y)
-        self.uv = take_all(capi.POOL_UV)
-        self.striped = [take_all(capi.POOL_STRIPED, g) for g in range(3)]
+    def _wrap(self, p):
+        t = as_tensor(p, CHUNK_BYTES, self.dev)
+        self._ptr[t.data_ptr()] = p
+        return t
+
+    def _take_all(self, kind, group=-1):
+        out = []
+        while self.pool.available(kind, group) > 0:
+            out.append(self._wrap(self.pool.alloc(kind, group)))
+        return out
 
     def group_of(self, t) -> int:
         return self.pool.group_of(t.data_ptr())
@@ -100,6 +102,25 @@ class HbmChunkPool:
             got, self.striped[g] = self._take(self.striped[g], n, "striped (group %d)" % g)
             out.append(got)
         return out
+
+    def take_rotating(self, n):
+        """n chunks for consecutive batches of PACKED frames through the C pool's own allocation mode (include/lumahip.h
+        LUMAHIP_POOL_ROTATING: consecutive allocations walk the region groups 0, 1, 2, 0, ...) -- the caller does not look at groups"""
+        from . import capi
+        for g in range(3):                       # what this wrapper holds of the striped chunks goes back into the C pool first
+            for t in self.striped[g]:
+                self.pool.release(self._ptr[t.data_ptr()])
+        self.striped = [[], [], []]
+        if self.pool.available(capi.POOL_ROTATING) < n:
+            self.striped = [self._take_all(capi.POOL_STRIPED, g) for g in range(3)]
+            raise RuntimeError("HbmChunkPool: %d rotating chunks wanted, fewer left" % n)
+        got = [self._wrap(self.pool.alloc(capi.POOL_ROTATING, 0 if i == 0 else -1)) for i in range(n)]
+        self.striped = [self._take_all(capi.POOL_STRIPED, g) for g in range(3)]
+        return got
+
+    def give_back_rotating(self, chunks):
+        for t in chunks:
+            self.striped[self.group_of(t)].insert(0, t)
 
     def give_back(self, floats, y, uv, striped=None):
         self.float = list(floats) + self.float
