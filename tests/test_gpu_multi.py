@@ -152,6 +152,32 @@ def test_bench_rccl_path_and_stream_mode():
 
 
 @pytest.mark.gpu
+def test_bench_under_the_launcher_at_n1_is_the_plain_run():
+    """The driver's scaling curve starts with N = 1 in the LAUNCHER form (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 1 ... bench.py --gpus 1): one rank with WORLD_SIZE=1 in its environment.  It must be the plain `python
+    bench.py` run -- same workload, same placement, same fields, no process group -- so that the N = 1 point of the curve and the
+    round's BENCH line are one measurement.  (The two values are printed; on the builder's boxes they agree within 1 %,
+    profiles/r05_torchrun_n1.txt.  Only a coarse band is asserted: hosts are shared.)"""
+    flags = ["--gpus", "1", "--steps", "10", "--warmup", "2", "--min-seconds", "0.3", "--no-cpu-baseline", "--no-other-workloads",
+             "--no-facade-hostfed", "--no-placement-off"]
+    plain = _bench(*flags)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + flags
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    launched = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=900)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
+    assert len([l for l in launched.stdout.splitlines() if l.startswith("{")]) == 1        # ONE JSON line under the launcher too
+    assert set(a) == set(b) and a["config"] == b["config"] and (a["n_gpus"], b["n_gpus"]) == (1, 1)
+    assert a["placement"]["mode"] == b["placement"]["mode"] and a["scaling"] == b["scaling"] == "weak"
+    print("plain %.0f Mpixel/s, under torch.distributed.run %.0f (ratio %.3f)" % (a["value"], b["value"], b["value"] / a["value"]))
+    assert 0.8 < b["value"] / a["value"] < 1.25
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     n = torch.cuda.device_count() + 1
