@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-placement-off", action="store_true", help="skip the value_placement_off leg (the same kernels on plain allocations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-coherent", action="store_true",
+                    help="skip the YCbCr workload's decode leg on a picture-like stream (the red / blue tables are read)")
     ap.add_argument("--no-float-inputs", action="store_true",
                     help="skip the float-input legs of the YCbCr workload (the same stream with full-precision mantissas / 1e-3 of them)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames the CPU baseline encodes (bounded sample, ~10 s on 1 thread)")
@@ -515,7 +517,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             r["roofline"] = enc_blk
             r["roofline"]["decode_achieved_GBs"] = dec_blk["achieved"]
             r["decode_roofline"] = dec_blk
-    if cs == 2 and rank == 0 and world == 1 and not args.no_float_inputs:
+    if cs == 2 and rank == 0 and world == 1 and not (args.no_float_inputs and args.no_decode_coherent):
         # ---- the same stream when its values are NOT binary16 (the reference's PFS pipe hands the encoder arbitrary floats,
         # src/pfs_interface.cpp:57-113): full-precision mantissas in every value, and in 1e-3 of the pixels, through the DEFAULT
         # policy (lumahip_tune half_table 1; lumahip_core.hip half_policy).  Last leg of the workload: it rewrites the stream.
@@ -551,7 +553,7 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                    "hbm_frac": round(BYTES_PER_PIXEL * px_step / (ms_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return blk, ms_own
 
-        if legs == "full":
+        if legs == "full" and not args.no_decode_coherent:
             # ---- decode of a PICTURE-like stream.  The legs above decode the planes of the synthetic stream, whose pixels are
             # unrelated: there no wave finds its codes local, the red / blue tables are never read (six powf per pixel,
             # and the launch-level policy soon picks the kernels without the test).  The same stream low-pass filtered in the log
@@ -582,16 +584,17 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             r["decode_random_rb_policy"] = {k: rb_after_random[k] for k in ("table_launches", "backoff_launches")}
             for b in range(nbatch):
                 ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
-        fblk, fms = float_leg(1.0, "every value with a full-precision mantissa (13 random low bits): no binary16 value in the stream")
-        fblk["roofline"] = valu_block(mixf, fms, {k: enc_blk[k] for k in ("peak", "unit", "algorithmic_bytes_per_launch")})
-        fblk["roofline"]["hbm"]["achieved"] = round(BYTES_PER_PIXEL * px_step / (fms * 1e-3) / 1e9, 1)
-        fblk["roofline"]["hbm"]["frac"] = fblk["hbm_frac"]
-        r["float_inputs"] = fblk
-        # (the stream above is all floats already; a fresh synthetic stream for the 1e-3 point)
-        for b in range(nbatch):
-            ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
-        mblk, _ = float_leg(1e-3, "1e-3 of the pixels with full-precision mantissas in all three channels, the rest binary16 values")
-        r["mixed_inputs_1e-3"] = mblk
+        if not args.no_float_inputs:
+            fblk, fms = float_leg(1.0, "every value with a full-precision mantissa (13 random low bits): no binary16 value in the stream")
+            fblk["roofline"] = valu_block(mixf, fms, {k: enc_blk[k] for k in ("peak", "unit", "algorithmic_bytes_per_launch")})
+            fblk["roofline"]["hbm"]["achieved"] = round(BYTES_PER_PIXEL * px_step / (fms * 1e-3) / 1e9, 1)
+            fblk["roofline"]["hbm"]["frac"] = fblk["hbm_frac"]
+            r["float_inputs"] = fblk
+            # (the stream above is all floats already; a fresh synthetic stream for the 1e-3 point)
+            for b in range(nbatch):
+                ctx.synth_frames_device(ptrs(b)[0], n3, B, w, h, SEED, first + b * B)
+            mblk, _ = float_leg(1e-3, "1e-3 of the pixels with full-precision mantissas in all three channels, the rest binary16 values")
+            r["mixed_inputs_1e-3"] = mblk
     ctx.close()
     if pool is not None:
         pool.give_back(src_c + out_c, y_c, uv_c, rgb_c)
