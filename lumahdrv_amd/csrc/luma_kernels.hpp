@@ -988,6 +988,9 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         }
         // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
         // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)
+        // (round 5, YCbCr: issuing these loads BEFORE the unit is processed, so that its powf chains cover their latency, is not
+        // faster -- 812 against 821 us per 20 x 4K with four pixels per thread, where it spills 17 VGPRs, and 938 against 798 with
+        // two: the waves do not wait for these loads, profiles/r05_ycbcr_decode_tables.txt)
         dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         cur = nxt;
     }

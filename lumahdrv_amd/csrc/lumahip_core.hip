@@ -272,6 +272,8 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
             return fail(c, LUMAHIP_ERR_ARG, "ycbcr_rb_tables must be 0 (six powf per pixel), 1 (red and blue from the per-stream tables where a wave's codes are close) or 2 (always)");
         c->rb_mode = (int)v;
         lag_policy_reset(c->rb_pol);
+    } else if (k == "dec_vw") {
+        c->dec_vw = v == 2 ? 2 : 0;
     } else if (k == "rb_near_y") {
         c->rb_near_y = (int)std::max<long>(0, std::min<long>(v, 1 << 24));
     } else if (k == "rb_near_c") {

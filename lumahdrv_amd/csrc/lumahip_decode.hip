@@ -201,6 +201,8 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     float *const *out = have_rgb ? rgb : none;
     const bool al16 = is_aligned(out[0], 16) && is_aligned(out[1], 16) && is_aligned(out[2], 16);
     int vw = (!gl && (w % 4) == 0 && al16 && (frame_stride % 4) == 0) ? 4 : 2;
+    if (c->dec_vw == 2)   // lumahip_tune("dec_vw", 2): two pixels per thread and row even where four are possible (measurements)
+        vw = 2;
     if (!is_aligned(out[0], 8) || !is_aligned(out[1], 8) || !is_aligned(out[2], 8) || (frame_stride % 2) != 0)
         return fail(c, LUMAHIP_ERR_ARG, "colour planes must be 8-byte aligned and the frame stride even");
     if (dp.rgba && (!is_aligned(dp.rgba, 4) || (dp.stride % 4) != 0 || (dp.frame_stride % 4) != 0 || dp.stride < (int)(4 * w)))

@@ -120,6 +120,7 @@ struct lumahip_ctx {
     LagPolicy rb_pol{false, 64};      // which kernel an eligible YCbCr decode launch takes (rb_mode 1): NO report = "no wave found its codes local"
     int rb_mode = 1;              // lumahip_tune("ycbcr_rb_tables"): 0 = six powf per pixel (rounds 3-4), 1 = red / blue from the tables where a
                                   // wave's codes are close to each other (luma_kernels.hpp rb_wave_near), 2 = from the tables always
+    int dec_vw = 0;               // lumahip_tune("dec_vw", 2): the decode kernels with two pixels per thread and row (0: four where alignment allows)
     int rb_near_y = 64, rb_near_c = 24;    // lumahip_tune("rb_near_y" / "rb_near_c"): the closeness bounds of mode 1 (luma_kernels.hpp rb_wave_local)
     bool force_literal = false;   // lumahip_tune("force_literal"): the reference's bisection instead of the records
     std::vector<float> h_lut;     // host copy of the table handed to lumahip_set_quantizer

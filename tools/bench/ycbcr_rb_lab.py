@@ -62,6 +62,8 @@ def main():
     lut = L.build_lut(ptf, bits, mx, mn)
     ctxs = {}
     variants = {"six_powf": (0, None), "adaptive": (1, None), "always": (2, None)}
+    if "--vw2" in args:   # two pixels per thread and row (75 VGPRs -> 6 waves per SIMD instead of 4)
+        variants = {"six_powf": (0, None), "six_vw2": (0, "vw2"), "always": (2, None), "always_vw2": (2, "vw2"), "adaptive_vw2": (1, "vw2")}
     if sweep:     # closeness bounds of the adaptive mode (luma_kernels.hpp rb_wave_local): luminance codes, colour codes
         variants = {"six_powf": (0, None), "always": (2, None)}
         for ny, nc in ((16, 8), (32, 12), (64, 24), (128, 48), (256, 96), (512, 200)):
@@ -69,7 +71,9 @@ def main():
     for key, (mode, near) in variants.items():
         c = L.Context(0)
         c.tune("ycbcr_rb_tables", mode)
-        if near:
+        if near == "vw2":
+            c.tune("dec_vw", 2)
+        elif near:
             c.tune("rb_near_y", near[0])
             c.tune("rb_near_c", near[1])
         c.set_stream(torch.cuda.current_stream().cuda_stream)
