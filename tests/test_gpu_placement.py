@@ -77,6 +77,10 @@ def test_pool_stream_cpp_example():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     # (no rate against rate: which of the two is faster, and by how much, is reported in profiles/, not asserted on a shared box)
     assert d["planes_identical"] is True and d["batches"] == 6 and d["pooled_mpix_s"] > 0 and d["plain_mpix_s"] > 0
+    # the decode half: packed LumaFrames in chunks the pool handed out in its ROTATING mode, same floats as in plain buffers
+    assert d["decoded_identical"] is True and d["decode_packed_rotating_mpix_s"] > 0 and d["decode_packed_plain_mpix_s"] > 0
+    if d["pool"].get("grouped"):
+        assert d["decode_ring_groups"] == [0, 1, 2, 0, 1, 2]
 
 
 def test_rotating_allocations_walk_the_region_groups():

@@ -9,8 +9,10 @@
 // 3. the same stream once more in plain lumahip_malloc buffers;
 // 4. both streams encoded alternately (passes interleaved, so clocks and temperature are shared), each pass = every batch
 //    once inside one unordered section; wall clock around lumahip_sync.
-// Prints one JSON line: Mpixel/s and fraction of the 8 TB/s roofline (15 B/pixel) for the pooled and the plain stream, and
-// whether the planes of the two streams are byte-identical (they must be: the pool only decides addresses).
+// 5. the stream decoded into PACKED LumaFrames whose buffers come from lumahip_pool_alloc(LUMAHIP_POOL_ROTATING) in stream
+//    order, against plain buffers.
+// Prints one JSON line: Mpixel/s and fraction of the 8 TB/s roofline (15 B/pixel) for the pooled and the plain stream, both
+// directions, and whether planes and decoded floats of the two are byte-identical (they must be: the pool only decides addresses).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -63,11 +65,13 @@ int main(int argc, char **argv)
         return 1;
     }
     const int ypc = (int)(CH / ybytes), uvpc = (int)(CH / uvbytes);
+    const int nring = std::min(nb, 6);   // packed decoded frames: a ring of output batches (>> the 256 MB MALL)
     lumahip_pool_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n_float = nb;
     cfg.n_y = (nb + ypc - 1) / ypc;
     cfg.n_uv = (nb + uvpc - 1) / uvpc;
+    cfg.n_striped = (nring + 2) / 3;     // per region group: what the ROTATING allocations below draw from
     lumahip_pool *pool = nullptr;
     const double tp0 = now();
     OK(lumahip_pool_create(ctx, &cfg, &pool));
@@ -145,11 +149,66 @@ int main(int argc, char **argv)
         OK(lumahip_memcpy_d2h(ctx, c.data(), plain.u[b], (size_t)B * psz[1]));
         same = same && std::memcmp(a.data(), c.data(), (size_t)B * psz[1]) == 0;
     }
+    // 5. decode, into PACKED LumaFrames (include/luma/luma_frame.h:84-87: what LumaDecoder::decode() returns): the output buffer of
+    //    every batch of a ring is allocated in stream order in the pool's ROTATING mode -- the caller does no group arithmetic --
+    //    against the same ring in plain lumahip_malloc buffers; passes interleaved as above.  Same floats either way.
+    std::vector<float *> rot(nring), pln(nring);
+    for (int k = 0; k < nring; k++) {
+        void *p = nullptr;
+        OK(lumahip_pool_alloc(pool, LUMAHIP_POOL_ROTATING, k == 0 ? 0 : -1, &p));
+        rot[k] = (float *)p;
+        OK(lumahip_malloc(ctx, &p, fbytes));
+        pln[k] = (float *)p;
+    }
+    auto dpass = [&](std::vector<float *> &out) -> int {
+        int rc = lumahip_begin_unordered(ctx, 0);
+        for (int b = 0; b < nb && rc == LUMAHIP_OK; b++) {
+            const unsigned char *pl[3] = {placed.y[b], placed.u[b], placed.v[b]};
+            rc = lumahip_decode_frames_device(ctx, pl, stride, psz, B, w, h, 2, 1.0f, out[b % nring], n3);
+        }
+        const int rc2 = lumahip_end_unordered(ctx);
+        const int rc3 = lumahip_sync(ctx);
+        return rc ? rc : (rc2 ? rc2 : rc3);
+    };
+    OK(dpass(rot));
+    OK(dpass(pln));
+    std::vector<double> dr, dq;
+    const double dstart = now();
+    while (now() - dstart < 2.0 || dr.size() < 5) {
+        double t0 = now();
+        OK(dpass(rot));
+        dr.push_back(now() - t0);
+        t0 = now();
+        OK(dpass(pln));
+        dq.push_back(now() - t0);
+    }
+    std::sort(dr.begin(), dr.end());
+    std::sort(dq.begin(), dq.end());
+    const double drr = px / dr[dr.size() / 2] / 1e6, drq = px / dq[dq.size() / 2] / 1e6;
+    bool dsame = true;
+    {
+        std::vector<float> fa(n3), fb(n3);   // the first frame of the last batch written into each ring slot... of slot 0
+        OK(lumahip_memcpy_d2h(ctx, fa.data(), rot[(nb - 1) % nring], n3 * sizeof(float)));
+        OK(lumahip_memcpy_d2h(ctx, fb.data(), pln[(nb - 1) % nring], n3 * sizeof(float)));
+        dsame = std::memcmp(fa.data(), fb.data(), n3 * sizeof(float)) == 0;
+    }
+    int groups[8];
+    for (int k = 0; k < nring && k < 8; k++)
+        groups[k] = lumahip_pool_group_of(pool, rot[k]);
+    char gbuf[64] = {0};
+    for (int k = 0, o = 0; k < nring && k < 8; k++)
+        o += std::snprintf(gbuf + o, sizeof gbuf - (size_t)o, "%s%d", k ? ", " : "", groups[k]);
     std::printf("{\"tool\": \"pool_stream\", \"batches\": %d, \"frames_per_batch\": %d, \"passes\": %zu, "
                 "\"pool_create_s\": %.2f, \"pooled_mpix_s\": %.0f, \"pooled_frac_of_8TBs\": %.4f, "
-                "\"plain_mpix_s\": %.0f, \"plain_frac_of_8TBs\": %.4f, \"planes_identical\": %s, \"pool\": %s}\n",
+                "\"plain_mpix_s\": %.0f, \"plain_frac_of_8TBs\": %.4f, \"planes_identical\": %s, "
+                "\"decode_packed_rotating_mpix_s\": %.0f, \"decode_packed_rotating_frac_of_8TBs\": %.4f, "
+                "\"decode_packed_plain_mpix_s\": %.0f, \"decode_packed_plain_frac_of_8TBs\": %.4f, \"decode_ring_groups\": [%s], "
+                "\"decoded_identical\": %s, \"pool\": %s}\n",
                 nb, B, tp.size(), pool_s, rp, rp * 15e6 / 8e12, rq, rq * 15e6 / 8e12, same ? "true" : "false",
-                lumahip_pool_stats_json(pool));
+                drr, drr * 15e6 / 8e12, drq, drq * 15e6 / 8e12, gbuf, dsame ? "true" : "false", lumahip_pool_stats_json(pool));
+    same = same && dsame;
+    for (int k = 0; k < nring; k++)
+        (void)lumahip_free(ctx, pln[k]);
     for (int b = 0; b < nb; b++) {
         (void)lumahip_free(ctx, plain.rgb[b]);
         (void)lumahip_free(ctx, plain.y[b]);
