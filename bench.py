@@ -376,8 +376,11 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
         pk = {}
         # "pool_rotating": batch b's packed frames in the b-th chunk the pool hands out in its ROTATING mode (region groups 0, 1,
         # 2, 0, ...), so that the launches in flight on the two lanes write different groups (profiles/r03_layout_lab.txt: 0.75)
-        for how in ("pool_placed", "pool_rotating", "plain"):
-            ring = rot = None
+        # "frame_rotating": the FRAMES of a batch rotate over three chunks of three region groups (frame f in chunk f % 3; every
+        # frame still a packed LumaFrame) and the launch interleaves its tiles over the frames, so ONE launch writes all three
+        # groups (lumahip_decode_frames_device_rotating): what the ordered figure of the packed layout can be
+        for how in ("pool_placed", "pool_rotating", "frame_rotating", "plain"):
+            ring = rot = frot = None
             if how == "pool_placed":
                 ring = pool.take_float(min(PACKED_RING, len(pool.float)))
                 if len(ring) < 3:
@@ -387,10 +390,20 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 if min(len(g) for g in pool.striped) < PACKED_RING // 3:
                     continue
                 rot = ring = pool.take_rotating(PACKED_RING)       # lumahip_pool_alloc(LUMAHIP_POOL_ROTATING): no group arithmetic here
+            elif how == "frame_rotating":
+                per = -(-B // 3)                                    # frames of a batch per chunk
+                if min(len(g) for g in pool.striped) < PACKED_RING // 3 or 3 * per * n3 * 4 > CHUNK_BYTES:
+                    continue
+                frot = pool.take_striped(PACKED_RING // 3)          # [[group 0 chunks], [group 1 chunks], [group 2 chunks]]
             plain = torch.empty(PACKED_RING * B * n3, dtype=torch.float32, device=dev) if how == "plain" else None
             nring = len(ring) if ring is not None else PACKED_RING
 
-            def dec_packed(i, ring=ring, plain=plain, nring=nring):
+            def dec_packed(i, ring=ring, plain=plain, nring=nring, frot=frot):
+                if frot is not None:
+                    k = i % nring
+                    bases = [frot[g][k // 3].data_ptr() + (k % 3) * (-(-B // 3)) * n3 * 4 for g in range(3)]
+                    ctx.decode_frames_device_rotating(ptrs(i % nbatch)[2], st, psz, B, w, h, profile, sc, bases, n3)
+                    return
                 o = ring[i % nring].data_ptr() if ring is not None else plain.data_ptr() + (i % nring) * B * n3 * 4
                 ctx.decode_frames_device_planar(ptrs(i % nbatch)[2], st, psz, B, w, h, profile, sc, [o + k * n1 * 4 for k in range(3)], n3)
 
@@ -402,7 +415,9 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             pk[how] = {"value": round(rate(tp["wall_median"]), 1), "value_ordered": round(rate(tpo["wall_median"]), 1),
                        "kernel_ms": round(tp["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(tpo["dev_ms_median"] / K, 4),
                        "frac_ordered": fr(tpo["dev_ms_median"] / K), "frac_overlapped": fr(tp["dev_ms_median"] / K), "batches_in_ring": nring}
-            if rot is not None:
+            if frot is not None:
+                pool.give_back([], [], [], frot)
+            elif rot is not None:
                 pool.give_back_rotating(rot)
             elif ring is not None:
                 pool.give_back(ring, [], [])
@@ -1057,9 +1072,10 @@ def main():
             "decode_mpix_s": r["decode_mpix_s"], "decode_output_layout": r["decode_output_layout"],
             "roundtrip_mpix_s": r["roundtrip_mpix_s"],
             "decode_packed_layout": r.get("decode_packed_layout"),
-            # the reference's own decode layout (LumaDecoder::decode() returns a packed LumaFrame) at its best placement: output chunks
-            # taken from the pool in its ROTATING mode, two launches in flight
-            "decode_packed_mpix_s": ((r.get("decode_packed_layout") or {}).get("pool_rotating") or {}).get("value"),
+            # the reference's own decode layout (LumaDecoder::decode() returns a packed LumaFrame) at its best placement: the frames of
+            # a batch rotating over three chunks of three region groups (lumahip_decode_frames_device_rotating), two launches in flight
+            "decode_packed_mpix_s": ((r.get("decode_packed_layout") or {}).get("frame_rotating") or {}).get("value"),
+            "decode_packed_frac": ((r.get("decode_packed_layout") or {}).get("frame_rotating") or {}).get("frac_ordered"),
             "kernel_source_sha": sha,
             "placement": dict({"mode": args.placement}, **(pool.stats if pool is not None else {})),
         }

@@ -276,6 +276,16 @@ int lumahip_encode_frames_device_planar(lumahip_ctx *ctx, const float *const rgb
 int lumahip_decode_frames_device_planar(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
                                         const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h,
                                         int profile, float sc, float *const rgb_planes_dev[3], size_t frame_stride);
+/* Decoded frames in the reference's PACKED layout (include/luma/luma_frame.h:84-87 there: channel c of a frame at base + c*w*h)
+ * spread over THREE buffers: frame f of the batch at bases[f % 3] + (f / 3) * frame_stride floats (frame_stride >= 3*w*h).  Every
+ * frame is a LumaFrame as LumaDecoder::decode() returns it; what changes is where consecutive frames live.  With the three
+ * buffers in three HBM region groups (lumahip_pool_alloc(pool, LUMAHIP_POOL_ROTATING, ...) three times) the launch walks its tiles
+ * interleaved over the frames, so the workgroups running at any moment write all three groups: one launch alone then reaches
+ * what the packed layout otherwise needs two launches in flight for (bench.py decode_packed_layout.frame_rotating).  Same floats
+ * as lumahip_decode_frames_device. */
+int lumahip_decode_frames_device_rotating(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                          const size_t plane_frame_stride[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                          float preScaling, float *const bases_dev[3], size_t frame_stride);
 
 /* Unordered section.  Frames -- and therefore batches of frames -- are independent in this path (the quantizer is
  * read-only state, src/luma_quantizer.cpp:215-264,267-482 keep nothing between frames), so a caller with several batches to

@@ -26,7 +26,7 @@ SYMBOLS = [
     "lumahip_encode_frame_host", "lumahip_decode_frame_host", "lumahip_encode_frames_host", "lumahip_decode_frames_host", "lumahip_pack_frame_host", "lumahip_unpack_frame_host", "lumahip_transform_color_space_host",
     "lumahip_quantize_array_host", "lumahip_dequantize_array_host", "lumahip_quantize_array_device", "lumahip_dequantize_array_device",
     "lumahip_encode_frames_device", "lumahip_mean_luminance_reference_device",
-    "lumahip_decode_frames_device", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
+    "lumahip_decode_frames_device", "lumahip_decode_frames_device_rotating", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
     "lumahip_device", "lumahip_encode_frames_device_planar", "lumahip_decode_frames_device_planar", "lumahip_begin_unordered", "lumahip_end_unordered",
     "lumahip_probe_decode_traffic_device",
     "lumahip_pool_create", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
@@ -164,6 +164,7 @@ def lib():
     L.lumahip_device.argtypes = [vp]
     L.lumahip_encode_frames_device_planar.argtypes = [vp, pp3, sz, u, u, u, f, i, pp3, ip3, sp3, vp]
     L.lumahip_decode_frames_device_planar.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, pp3, sz]
+    L.lumahip_decode_frames_device_rotating.argtypes = [vp, pp3, ip3, sp3, u, u, u, i, f, pp3, sz]
     L.lumahip_begin_unordered.argtypes = [vp, i]
     L.lumahip_end_unordered.argtypes = [vp]
     L.lumahip_probe_decode_traffic_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, pp3, sz, i, C.POINTER(f)]
@@ -590,6 +591,12 @@ class Context:
         self._chk(self.L.lumahip_encode_frames_device_planar(self.h, _arr3(C.c_void_p, rgb_plane_ptrs), frame_stride, nframes, w, h,
                                                              sc, profile, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
                                                              _arr3(C.c_size_t, plane_frame_strides), stats_ptr))
+
+    def decode_frames_device_rotating(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, profile, sc, base_ptrs, frame_stride):
+        """packed frames over three buffers: frame f at base_ptrs[f % 3] + (f // 3) * frame_stride floats"""
+        self._chk(self.L.lumahip_decode_frames_device_rotating(self.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                               _arr3(C.c_size_t, plane_frame_strides), nframes, w, h, profile, sc,
+                                                               _arr3(C.c_void_p, base_ptrs), frame_stride))
 
     def decode_frames_device_planar(self, plane_ptrs, strides, plane_frame_strides, nframes, w, h, profile, sc, rgb_plane_ptrs,
                                     frame_stride):

@@ -35,6 +35,8 @@ struct FrameGeom {
     int tilesX, tilesY;  // ceil(unitsX/64), ceil(unitsY/NW)
     int tilesPerFrame;
     int totalTiles;      // tilesPerFrame * nframes
+    int nframes;
+    int interleave;      // 0: tiles in frame-major order; 1: tile t belongs to frame t % nframes (DecArgs::rot says why)
 };
 
 struct EncArgs {
@@ -66,6 +68,12 @@ struct DecArgs {
     size_t src_frame_stride[3];
     float *dst[3];        // colour plane c of frame f at dst[c] + f*frame_stride; dst[0] null when only the display output is wanted
     size_t frame_stride;
+    // rot_on: PACKED frames (LumaFrame layout, channel c at base + c*w*h) spread over three buffers, frame f at
+    // rot[f % 3] + (f / 3) * frame_stride -- with the three buffers in three HBM region groups and the tiles of a launch interleaved
+    // over its frames (FrameGeom::interleave), the workgroups running at any moment write all three groups, which one launch
+    // that writes a batch of packed frames into ONE buffer cannot (lumahip_decode_frames_device_rotating)
+    float *rot[3];
+    int rot_on;
     float sc;
     int bps;
     int aligned;
@@ -330,8 +338,14 @@ LH_DEV void store_px(float *p, const float (&v)[VW])
 
 LH_DEV void tile_coords(int t, const FrameGeom &g, int &f, int &bx, int &by)
 {
-    f = t / g.tilesPerFrame;
-    const int r = t - f * g.tilesPerFrame;
+    int r;
+    if (g.interleave) {   // (kernel argument: uniform; all of this is scalar arithmetic)
+        r = t / g.nframes;
+        f = t - r * g.nframes;
+    } else {
+        f = t / g.tilesPerFrame;
+        r = t - f * g.tilesPerFrame;
+    }
     by = r / g.tilesX;
     bx = r - by * g.tilesX;
 }
@@ -889,11 +903,23 @@ LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k,
     }
 
     if (!DISP || a.dst[0]) {
-        const size_t off = (size_t)u.f * a.frame_stride + (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+        const size_t px = (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
+        if (a.rot_on) {   // (kernel argument: uniform; u.f is wave-uniform, so the base is a scalar select)
+            const int k = u.f / 3, j = u.f - 3 * k;
+            float *base = (j == 0 ? a.rot[0] : j == 1 ? a.rot[1] : a.rot[2]) + (size_t)k * a.frame_stride + px;
+            const size_t n1 = (size_t)a.g.w * a.g.h;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            store_px<VW>(a.dst[c] + off, out[c][0]);
-            store_px<VW>(a.dst[c] + off + a.g.w, out[c][1]);
+            for (int c = 0; c < 3; c++) {
+                store_px<VW>(base + c * n1, out[c][0]);
+                store_px<VW>(base + c * n1 + a.g.w, out[c][1]);
+            }
+        } else {
+            const size_t off = (size_t)u.f * a.frame_stride + px;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                store_px<VW>(a.dst[c] + off, out[c][0]);
+                store_px<VW>(a.dst[c] + off + a.g.w, out[c][1]);
+            }
         }
     }
     if constexpr (DISP) {

@@ -981,6 +981,8 @@ bool make_geom(FrameGeom &g, unsigned w, unsigned h, int vw, int nw, unsigned nf
     g.tilesX = (g.unitsX + 63) / 64;
     g.tilesY = (g.unitsY + nw - 1) / nw;
     g.tilesPerFrame = g.tilesX * g.tilesY;
+    g.nframes = (int)nframes;
+    g.interleave = 0;
     const long long total = (long long)g.tilesPerFrame * nframes;
     if (w > 0x7fffffffu / 4 || h > 0x7fffffffu / 4 || total > 0x7fffffffLL)
         return false;  // tile indices are 32-bit

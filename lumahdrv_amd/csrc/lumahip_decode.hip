@@ -182,16 +182,32 @@ int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
 }
 
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
-                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
-                const DisplayParams &dp, int cs_eff, bool lanes)
+                unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb_in[3], size_t frame_stride,
+                const DisplayParams &dp, int cs_eff, bool lanes, float *const rot[3])
 {
+    // rot: packed frames rotating over three buffers (DecArgs::rot); the checks below then look at buffer 0's first frame
+    float *rot_planes[3] = {nullptr, nullptr, nullptr};
+    if (rot) {
+        if (!rot[0] || !rot[1] || !rot[2] || dp.rgba)
+            return fail(c, LUMAHIP_ERR_ARG, "null argument");
+        if (frame_stride < (size_t)3 * w * h)
+            return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < 3*w*h = %zu floats (packed frames)", frame_stride, (size_t)3 * w * h);
+        for (int k = 0; k < 3; k++) {
+            if (!is_aligned(rot[k], 16) && ((w % 4) == 0))
+                return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must be 16-byte aligned");
+            rot_planes[k] = rot[0] + (size_t)k * w * h;
+        }
+        if (rot[0] == rot[1] || rot[1] == rot[2] || rot[0] == rot[2])
+            return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must be distinct");
+    }
+    float *const *rgb = rot ? rot_planes : rgb_in;
     const bool have_rgb = rgb && rgb[0];
     if (!c || (!have_rgb && !dp.rgba) || (have_rgb && (!rgb[1] || !rgb[2])) || !planes || !stride || !pfs || nframes == 0)
         return fail(c, LUMAHIP_ERR_ARG, "null argument");
     int rc = check_geom(c, w, h, profile, cs_eff);
     if (rc)
         return rc;
-    if ((rc = check_layout(c, w, h, profile, nframes, have_rgb ? rgb : nullptr, frame_stride, stride, pfs)))
+    if ((rc = check_layout(c, w, h, profile, nframes, (have_rgb && !rot) ? rgb : nullptr, frame_stride, stride, pfs)))
         return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const bool sub = (profile == 0 || profile == 2);
@@ -220,6 +236,12 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     for (int k = 0; k < 3; k++)
         a.dst[k] = out[k];
+    if (rot) {
+        for (int k = 0; k < 3; k++)
+            a.rot[k] = rot[k];
+        a.rot_on = 1;
+        a.g.interleave = 1;
+    }
     a.frame_stride = frame_stride;
     a.sc = sc;
     a.bps = bps;
@@ -265,7 +287,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     // colour planes of the batch are separate buffers (no plane starts inside another plane's extent over the batch) -- the layout
     // a caller uses to spread the three write streams over the HBM region groups (lumahip_decode_frames_device_planar)
     int few_writers = (sub && bps == 2 && cs_eff != CS_YCBCR && dp.rgba == nullptr) ? 1 : 0;
-    if (few_writers && have_rgb && planes_are_separate_buffers(rgb, frame_stride, nframes, w, h))
+    if (few_writers && have_rgb && (rot || planes_are_separate_buffers(rgb, frame_stride, nframes, w, h)))
         few_writers = 2;
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, few_writers, cs_eff == CS_YCBCR);
     hipStream_t s = launch_stream(c, lanes);
@@ -344,6 +366,17 @@ extern "C" int lumahip_decode_frames_device(lumahip_ctx *c, const unsigned char 
     const size_t n = (size_t)w * h;
     float *const pl[3] = {rgb, rgb + n, rgb + 2 * n};
     return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, pl, frame_stride, DisplayParams(), c->q.cs, true);
+}
+
+extern "C" int lumahip_decode_frames_device_rotating(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],
+                                                     const size_t pfs[3], unsigned nframes, unsigned w, unsigned h, int profile,
+                                                     float sc, float *const bases[3], size_t frame_stride)
+{
+    if (!c)
+        return LUMAHIP_ERR_ARG;
+    if (!bases)
+        return fail(c, LUMAHIP_ERR_ARG, "null argument");
+    return decode_impl(c, planes, stride, pfs, nframes, w, h, profile, sc, nullptr, frame_stride, DisplayParams(), c->q.cs, true, bases);
 }
 
 extern "C" int lumahip_decode_frames_device_planar(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3],

@@ -300,7 +300,8 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
 bool encode_supports_in16(lumahip_ctx *c, unsigned w);
 int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int stride[3], const size_t pfs[3],
                 unsigned nframes, unsigned w, unsigned h, int profile, float sc, float *const rgb[3], size_t frame_stride,
-                const DisplayParams &dp, int cs_eff, bool lanes = false);
+                const DisplayParams &dp, int cs_eff, bool lanes = false, float *const rot[3] = nullptr);
+// rot: PACKED frames rotating over three buffers, frame f at rot[f % 3] + (f / 3) * frame_stride (rgb is then ignored)
 // lanes: the call is one of the four _device encode / decode entry points and goes to a lane of an open unordered section;
 // every other caller (the _host entry points with their own upload / kernel / download streams, the stream push / pop, the
 // display decode) stays on c->stream whether a section is open or not, as include/lumahip.h promises

@@ -108,7 +108,7 @@ def test_bench_contract_single_gpu():
         assert r["value_placement_off"] > 0
         # the reference's decoder returns the packed LumaFrame: that layout's decode rate, pool-placed and plainly allocated
         pk = r["decode_packed_layout"]
-        for how in ("pool_placed", "plain"):
+        for how in ("pool_placed", "pool_rotating", "frame_rotating", "plain"):
             assert pk[how]["value"] > 0 and 0 < pk[how]["frac_ordered"] < 1 and pk[how]["kernel_ms_ordered"] > 0, pk
     assert "facade_hostfed" not in r                      # (--no-facade-hostfed: that leg has its own test below)
 

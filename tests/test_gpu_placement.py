@@ -131,3 +131,48 @@ def test_rotating_allocations_walk_the_region_groups():
     pool.close()
     ctx.set_stream(None)
     ctx.close()
+
+
+def test_packed_frames_rotating_over_three_buffers_equal_the_packed_batch(oracle_mod):
+    """lumahip_decode_frames_device_rotating: frame f of the batch at bases[f % 3] + (f // 3) * frame_stride, tiles interleaved over the
+    frames.  Every frame must hold the floats lumahip_decode_frames_device writes for it -- Lu'v' and YCbCr (its own kernels), 4:2:0
+    and 4:4:4, widths with four and two pixels per thread, batches of 1, 2, 3 and 7 frames (not multiples of three) -- and frame 0
+    the oracle's."""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    for cfg, sc in (((L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005), 1.0), ((L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01), 20.0)):
+        ctx = L.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+        orc = o.Oracle(*cfg)
+        for (w, h), profile, B in (((640, 96), 2, 7), ((258, 34), 2, 3), ((256, 64), 3, 2), ((64, 32), 2, 1)):
+            n1, n3 = w * h, 3 * w * h
+            _, hs, st, _ = L.plane_geometry(w, h, profile)
+            psz = [hs[p] * st[p] for p in range(3)]
+            src = torch.empty(B * n3, dtype=torch.float32, device=dev)
+            planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+            ctx.synth_frames_device(src.data_ptr(), n3, B, w, h, 11, 0)
+            pl = [p.data_ptr() for p in planes]
+            ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, sc, profile, pl, st, psz)
+            ref = torch.empty(B * n3, dtype=torch.float32, device=dev)
+            ctx.decode_frames_device(pl, st, psz, B, w, h, profile, sc, ref.data_ptr(), n3)
+            per = -(-B // 3)
+            fs = n3 + 64                                              # frames of one buffer a little apart
+            bufs = [torch.full((per * fs,), float("nan"), dtype=torch.float32, device=dev) for _ in range(3)]
+            ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, [b.data_ptr() for b in bufs], fs)
+            torch.cuda.synchronize()
+            for f in range(B):
+                got = bufs[f % 3][(f // 3) * fs:(f // 3) * fs + n3]
+                assert torch.equal(got.view(torch.int32), ref[f * n3:(f + 1) * n3].view(torch.int32)), (cfg[2], (w, h), profile, B, f)
+            for b_ in bufs:                                           # nothing written between or behind the frames
+                gaps = b_.view(per, fs)[:, n3:]
+                assert bool(torch.isnan(gaps).all())
+            pf = [planes[p][:psz[p]].cpu().numpy().reshape(hs[p], st[p]) for p in range(3)]
+            exp = orc.decode(pf, st, w, h, sc, profile)
+            assert np.array_equal(bufs[0][:n3].cpu().numpy().view(np.uint32), exp.reshape(-1).view(np.uint32))
+        with pytest.raises(L.LumaHipError):                           # one buffer twice
+            ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, [bufs[0].data_ptr(), bufs[0].data_ptr(), bufs[2].data_ptr()], n3)
+        ctx.set_stream(None)
+        ctx.close()
