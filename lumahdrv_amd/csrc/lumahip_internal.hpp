@@ -106,7 +106,7 @@ struct lumahip_ctx {
     };
     std::vector<HalfTab> half_tabs;
     unsigned long half_clock = 0;
-    int half_mode = 1;            // lumahip_tune("half_table"): 0 = never, 1 = while the stream looks like binary16 data (half_policy), 2 = always
+    int half_mode = 1;            // lumahip_tune("half_table"): 0 = never, 1 = while the stream looks like binary16 data (half_pol: LagPolicy), 2 = always
     LagPolicy half_pol{true, 1024};     // which kernel an eligible YCbCr encode launch takes (half_mode 1): a report = "these are not halves"
     unsigned long half_launches = 0;
     // YCbCr decode: device copies of the per-stream red / blue tables (lumahip_decode.hip rb_table_for), one per preScaling seen

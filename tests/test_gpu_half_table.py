@@ -156,7 +156,7 @@ def test_pairs_without_a_table_and_the_table_cache(oracle_mod):
 
 
 def _half_policy_model(kinds, lag=4, longest=1024):
-    """lumahip_core.hip half_policy restated: kinds[i] = True when eligible launch i holds full-precision floats (a table launch on
+    """lumahip_core.hip lag_policy_next (LagPolicy, lumahip_internal.hpp) restated: kinds[i] = True when eligible launch i holds full-precision floats (a table launch on
     it reports).  Returns, per launch, (table launches so far, back-off launches so far) AFTER it was issued."""
     ON, BACKOFF, PROBE_WAIT = 0, 1, 2
     state, left, length, pending, table, backoff, out = ON, 0, 0, [], 0, 0, []
