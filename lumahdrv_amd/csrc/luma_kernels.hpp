@@ -55,7 +55,7 @@ struct EncArgs {
     const float *half;    // LM == 6 only: the half-input table of this (sc, Lmax), HALF_TABLE_LEN floats padded to 16 B (luma_device.hpp half_lookup)
     // LM == 6 only, nullable: THIS launch's word in host-visible memory, which a workgroup sets to 1 when every unit of every
     // one of its waves held inputs that are not halves -- the stream is not binary16 data and the host stops picking this
-    // kernel for a while (lumahip_core.hip half_policy reads the word after the launch's completion event).  Feedback only:
+    // kernel for a while (LagPolicy, lumahip_internal.hpp: the host reads the word after the launch's completion event).  Feedback only:
     // nothing a launch computes depends on it.
     uint32_t *half_flag;
 };

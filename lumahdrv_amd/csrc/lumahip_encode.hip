@@ -149,7 +149,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     const bool ycode = !in16 && cs_eff == CS_YCBCR && !stats && ycbcr_composite_ready(c);
     // ... and R', G', B' of binary16 inputs from the half-input table of this call's (sc, Lmax), when table + records fit the LDS
     const float *half = nullptr;
-    uint32_t *half_flag = nullptr;   // this launch's feedback word (half_policy)
+    uint32_t *half_flag = nullptr;   // this launch's feedback word (LagPolicy)
     if (ycode && c->half_mode != 0 && lds_bytes(c, true, cs_eff, true, true) <= LUMAHIP_LDS_PER_WORKGROUP) {
         if ((rc = half_table_for(c, sc, &half)))
             return rc;
