@@ -7,6 +7,7 @@ run with `-x` has compared every configuration with the reference's results befo
   C1  test_survey_testframe_digests           ExrInterface::testFrame 1920x1080 (and 1280x720), test_simple_enc parameters;
                                               the digests come from the complete reference encoder
   C2  test_full_size_4k_frame_and_properties  3840x2160 PQ-11 Lu'v' encode + decode, bit-exact, plus size-independent properties
+      test_config2_full_500_frame_stream_round_trip   the whole 500-frame stream, encode + decode through all three decode entry points
   C3  test_full_size_other_configs[pq10_ycbcr10]   HDR10 recipe, 4K
   C4  test_full_size_other_configs[log12_luv8]     7680x4320 LOG-12
   C5  test_config5_full_size_stream           the 2000-frame 4K stream, block-sharded over the GPUs the box has
@@ -83,6 +84,64 @@ def test_full_size_4k_frame_and_properties(L, oracle_mod):
     y2 = planes2[0][:sizes[0]].cpu().numpy().view("<u2").astype(np.int32)
     assert np.mean(np.abs(y1 - y2) <= 1) > 0.999
     q.ctx.set_stream(None)
+
+
+def test_config2_full_500_frame_stream_round_trip(L, oracle_mod):
+    """BASELINE configs[1] as written: the 500-frame 3840x2160 PQ-11 Lu'v' synthetic stream, resident, encoded and decoded in batches
+    of 20.  Frames 0, 123, 250 and 499: planes and decoded floats bit-equal to the oracle's.  ALL 500 frames: the decoded stream is the
+    same bits through the three decode entry points (packed in one buffer, R / G / B planes in three buffers, packed frames rotating
+    over three buffers), and re-encoding the decoded frames reproduces the luminance codes (>= 99.9 % within one code: decoded colours
+    outside the gamut clamp, as in the single-frame test above)."""
+    import torch
+    o = oracle_mod
+    w, h, B, F = 3840, 2160, 20, 500
+    free = torch.cuda.mem_get_info(0)[0]
+    if free < 150e9:
+        pytest.skip("needs 150 GB of free HBM")
+    q, orc = pair(L, o, CONFIGS["pq11_luv8"])
+    c = q.ctx
+    dev = torch.device("cuda:0")
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    n1, n3 = w * h, 3 * w * h
+    _, hs, st, _ = L.plane_geometry(w, h, 2)
+    psz = [hs[p] * st[p] for p in range(3)]
+    src = torch.empty(F * n3, dtype=torch.float32, device=dev)
+    dec = torch.empty(F * n3, dtype=torch.float32, device=dev)
+    planes = [torch.zeros(F * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    planes2 = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    alt = torch.empty(B * n3, dtype=torch.float32, device=dev)            # one batch through the other two entry points
+    per = -(-B // 3)
+    rot = [torch.empty(per * n3, dtype=torch.float32, device=dev) for _ in range(3)]
+    close = total = 0
+    for b in range(F // B):
+        sp, dp = src.data_ptr() + b * B * n3 * 4, dec.data_ptr() + b * B * n3 * 4
+        pl = [planes[p].data_ptr() + b * B * psz[p] for p in range(3)]
+        c.synth_frames_device(sp, n3, B, w, h, 20250929, b * B)
+        c.encode_frames_device(sp, n3, B, w, h, 1.0, 2, pl, st, psz)
+        c.decode_frames_device(pl, st, psz, B, w, h, 2, 1.0, dp, n3)
+        # the same batch as three colour-plane buffers (channel-major: plane c of frame f at alt + c*B*n1 + f*n1) ...
+        c.decode_frames_device_planar(pl, st, psz, B, w, h, 2, 1.0, [alt.data_ptr() + k * B * n1 * 4 for k in range(3)], n1)
+        # ... and as packed frames rotating over three buffers
+        c.decode_frames_device_rotating(pl, st, psz, B, w, h, 2, 1.0, [r.data_ptr() for r in rot], n3)
+        c.encode_frames_device(dp, n3, B, w, h, 1.0, 2, [x.data_ptr() for x in planes2], st, psz)
+        torch.cuda.synchronize()
+        d = dec[b * B * n3:(b + 1) * B * n3].view(B, 3, n1)
+        assert torch.equal(alt.view(3, B, n1).permute(1, 0, 2).view(torch.int32), d.view(torch.int32)), b
+        for f in range(B):
+            assert torch.equal(rot[f % 3][(f // 3) * n3:(f // 3 + 1) * n3].view(torch.int32), d[f].reshape(-1).view(torch.int32)), (b, f)
+        y1 = planes[0][b * B * psz[0]:(b + 1) * B * psz[0]].view(torch.int16).to(torch.int32)
+        y2 = planes2[0].view(torch.int16).to(torch.int32)
+        close += int(((y1 - y2).abs() <= 1).sum().item())
+        total += y1.numel()
+    assert close / total > 0.999
+    nthreads = min(64, os.cpu_count() or 8)
+    for f in (0, 123, 250, 499):
+        e, _, _ = orc.encode(o.synth_frame(w, h, 20250929, f), 1.0, 2, threads=nthreads)
+        for p in range(3):
+            got = planes[p][f * psz[p]:(f + 1) * psz[p]].cpu().numpy().reshape(hs[p], st[p])
+            assert np.array_equal(got, e[p]), (f, p)
+        assert same_bits(dec[f * n3:(f + 1) * n3].cpu().numpy().reshape(3, h, w), orc.decode(e, st, w, h, 1.0, 2, threads=nthreads)), f
+    c.set_stream(None)
 
 
 @pytest.mark.parametrize("name,w,h,sc", [("log12_luv8", 7680, 4320, 1.0), ("pq10_ycbcr10", 3840, 2160, 20.0)])
