@@ -662,10 +662,14 @@ def run_stream(L, args, rank, world, local_rank, use_dist, dev):
     if plan["pool"] is not None:
         pool = make_pool(L, args, dev, local_rank, w, h, B, nbatches=steps, with_output=False)
     if pool is not None:
-        # step k's frames in chunk k of the pool's float chunks; Y and U / V planes in their own chunks (placement.py)
         from lumahdrv_amd.placement import CHUNK_BYTES, slots
         ypc, yslot = slots(CHUNK_BYTES, B * psz[0])
         uvpc, uvslot = slots(CHUNK_BYTES, B * psz[1] + (1 << 20) + B * psz[2])
+        if len(pool.float) < steps or len(pool.y) < -(-steps // ypc) or len(pool.uv) < -(-steps // uvpc):
+            pool.close()                       # (the driver gave fewer chunks than the plan asked for: plain allocations)
+            pool = None
+    if pool is not None:
+        # step k's frames in chunk k of the pool's float chunks; Y and U / V planes in their own chunks (placement.py)
         src_c, y_c, uv_c = pool.take_float(steps), pool.take_y(-(-steps // ypc)), pool.take_uv(-(-steps // uvpc))
         vo = (B * psz[1] + (1 << 20) - 1) // (1 << 20) * (1 << 20)
 
@@ -906,8 +910,14 @@ def stream_shard_plan(F, rank, world, w, h, B, free, placement="auto", profile=2
     per_frame = n3 * 4 + sum(psz)
     resident = per_frame * max(nfr, 1)
     steps = (nfr + B - 1) // B
-    use_pool = placement == "auto" and 8e9 <= per_frame * nfr <= free * 0.6      # (a few GB: not worth probing 280 GB for)
-    req = pool_request(w, h, B, nbatches=steps, with_output=False) if use_pool and steps else None
+    # the pool when the shard is worth probing for (a few GB are not) and its chunks fit what is free: a 2000-frame shard (N = 1:
+    # 130 of the ~140 chunks of a 288 GB GPU) takes its float chunks from all three region groups -- half of its batches then read
+    # where their planes are written, which is still no worse than what plain allocations pair at random
+    req = pool_request(w, h, B, nbatches=steps, with_output=False) if (placement == "auto" and steps and per_frame * nfr >= 8e9) else None
+    if req is not None:
+        need = req["n_float"] + req["n_y"] + req["n_uv"]
+        if need * req["chunk_bytes"] > free - (8 << 30):
+            req = None
     return {"rank": rank, "first_frame": mine.start, "frames": nfr, "steps": steps, "bytes_resident": resident,
             "input_bytes": n3 * 4 * nfr, "plane_bytes": sum(psz) * nfr, "free_bytes": int(free), "fits": resident <= free * 0.9,
             "pool": req, "placement": "chunk pool" if req else "plain allocations"}
