@@ -177,14 +177,15 @@ def test_full_size_other_configs(L, oracle_mod, name, w, h, sc):
 @pytest.mark.parametrize("driver", ["torch", "multi"])
 def test_config5_full_size_stream(driver, oracle_mod, tmp_path):
     """BASELINE configs[4] at FULL size on whatever GPUs this box has: the 2000-frame 3840x2160 PQ-11 Lu'v' stream, resident
-    (249 GB at N = 1), block-sharded, through bench.py's one-process-per-GPU driver and through the C ABI's many-GPU layer
+    (249 GB at N = 1; in consecutive resident blocks where a GPU has less free), block-sharded, through bench.py's one-process-per-GPU driver and through the C ABI's many-GPU layer
     (--driver multi).  The stream digest is independent of the driver and of N and equals the committed one
     (profiles/r02_stream2000_n1.json); four frames are checked against the oracle's planes."""
     import importlib.util
     import torch
-    free = sum(torch.cuda.mem_get_info(d)[0] for d in range(torch.cuda.device_count()))
-    if free < 262e9:
-        pytest.skip("needs >= 262 GB of free HBM for the resident 2000-frame stream (have %.0f GB)" % (free / 1e9))
+    free = min(torch.cuda.mem_get_info(d)[0] for d in range(torch.cuda.device_count()))
+    if free < 30e9:
+        pytest.skip("needs >= 30 GB of free HBM per GPU (have %.0f GB)" % (free / 1e9))
+    # (a GPU that cannot hold its whole shard at once -- 249 GB at N = 1 -- encodes it in consecutive resident blocks: same digest)
     n = torch.cuda.device_count()
     dump = str(tmp_path / "digests.json")
     p = _bench("--gpus", str(n), "--stream-frames", "2000", "--driver", driver, "--min-seconds", "0.2", "--dump-digests", dump)

@@ -108,8 +108,11 @@ def test_bench_contract_single_gpu():
         assert r["value_placement_off"] > 0
         # the reference's decoder returns the packed LumaFrame: that layout's decode rate, pool-placed and plainly allocated
         pk = r["decode_packed_layout"]
+        # (a box with little free HBM gives the pool too few chunks for some of these legs: they are then absent, never wrong)
+        assert "plain" in pk
         for how in ("pool_placed", "pool_rotating", "frame_rotating", "plain"):
-            assert pk[how]["value"] > 0 and 0 < pk[how]["frac_ordered"] < 1 and pk[how]["kernel_ms_ordered"] > 0, pk
+            if how in pk:
+                assert pk[how]["value"] > 0 and 0 < pk[how]["frac_ordered"] < 1 and pk[how]["kernel_ms_ordered"] > 0, pk
     assert "facade_hostfed" not in r                      # (--no-facade-hostfed: that leg has its own test below)
 
 

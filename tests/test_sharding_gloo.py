@@ -286,7 +286,11 @@ def test_bench_plan_only_for_eight_gpus():
     # N = 1 holds the whole stream (249 GB): fits, but leaves no room for the pool; 3000 frames do not fit and the exit code says so
     rc, d = _plan(["--gpus", "1", "--stream-frames", "2000"])
     assert rc == 0 and d["ranks"][0]["placement"] == "plain allocations" and d["ranks"][0]["bytes_resident"] == 2000 * (n3 * 4 + 3 * 3840 * 2160)
+    # 3000 frames on one GPU do not fit at once: the shard is encoded in two resident blocks (exit code 0); a frame that does not
+    # fit at all is an error (exit code 1)
     rc, d = _plan(["--gpus", "1", "--stream-frames", "3000"])
+    assert rc == 0 and d["fits"] and not d["ranks"][0]["fits"] and d["ranks"][0]["segments"] == 2
+    rc, d = _plan(["--gpus", "1", "--stream-frames", "40", "--width", "65536", "--height", "65536", "--frames-per-step", "4"])
     assert rc == 1 and not d["fits"]
     # uneven: 37 frames over 8 ranks
     rc, d = _plan(["--gpus", "8", "--stream-frames", "37"])
