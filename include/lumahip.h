@@ -148,7 +148,8 @@ int lumahip_half_table_info(lumahip_ctx *ctx, float sc, int info[6]);
 /* Red / blue tables of the YCbCr decode kernels.  A decoded pixel's red depends on its luminance code and its Cr code only, its
  * blue on the luminance code and the Cb code (src/luma_quantizer.cpp:447-451, 460-468: y + chroma term, clamp, PQdec, / sc), so per
  * stream and preScaling the library tabulates both on the device (2 x 2^(bitdepth + bitdepthC) floats: 8 MiB for the HDR10
- * recipe; only while that stays within 16 MiB; built by one launch with the same complete functions the kernels fall back to)
+ * recipe, 128 MiB for 12-bit luminance and colour; not beyond 256 MiB; built by one launch with the same complete functions the
+ * kernels fall back to)
  * and the kernels replace four of a pixel's six powf by two 4-byte gathers from global memory (L1 / L2) -- where the gathers are
  * cheap: a wave first checks that most of its lanes' codes are close to their neighbours' (a picture), else it
  * computes all three channels as before.  Results are identical either way.  lumahip_tune("ycbcr_rb_tables", v): 0 = never,

@@ -137,8 +137,9 @@ static bool planes_are_separate_buffers(float *const rgb[3], size_t frame_stride
 // The device red / blue tables of this call's preScaling (nullptr: not for this stream).  Built by one launch of k_build_rb the
 // first time a preScaling is seen (two tables of 2^(bitdepth + bitdepthC) floats: 8 MiB for the HDR10 recipe, ~20 us), kept per
 // context -- up to two preScalings; launches that read an older copy may still be queued anywhere, so making room waits for the
-// device first.  Only streams whose tables stay within RB_MAX_BYTES (they must live in L2 / MALL to be worth reading).
-static constexpr size_t RB_MAX_BYTES = (size_t)16 << 20;
+// device first.  What a gather costs is the L1 hit rate of the lines a picture touches, not the size of the table: PQ-12 with
+// 12-bit colour (2 x 64 MiB) is read as profitably as the HDR10 recipe's 8 MiB; beyond RB_MAX_BYTES the tables are not built.
+static constexpr size_t RB_MAX_BYTES = (size_t)256 << 20;
 
 int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
 {

@@ -98,8 +98,19 @@ def test_tables_follow_the_quantizer_and_the_prescaling(oracle_mod):
             exp = orc.decode(planes, st, 256, 64, sc, 2)
             assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (cfg, sc)
         assert q.ctx.rb_table_info(1.0)["used"]
-    # deeper than 2^20 (Y, C) pairs x 2 tables x 4 B > 16 MiB: no tables, the plain kernels
-    q.setQuantizer(1, 12, 2, 10, 1000.0, 0.01)
+    # 12-bit luminance and colour: 2 x 64 MiB of tables, still read (what matters is the L1 hit rate of the lines a picture touches)
+    cfg12 = (1, 12, 2, 12, 1000.0, 0.01)
+    q.setQuantizer(*cfg12)
+    info = q.ctx.rb_table_info(20.0)
+    assert info["used"] and info["bytes"] == 2 * (1 << 24) * 4
+    orc = o.Oracle(*cfg12)
+    y12, cb12, cr12 = [np.minimum(a.astype(np.uint32) * 4 + 1, 4095).astype(np.uint16) for a in (y, cb, cr)]
+    planes, st = _planes_from_codes(L, y12, cb12, cr12, 2)
+    got = q.ctx.decode_frame(planes, st, 256, 64, 20.0, 2)
+    assert np.array_equal(got.view(np.uint32), orc.decode(planes, st, 256, 64, 20.0, 2).view(np.uint32))
+    assert q.ctx.rb_table_info(20.0)["table_launches"] > 0
+    # 14-bit luminance with 12-bit colour would be 2 x 256 MiB: no tables, the plain kernels
+    q.setQuantizer(1, 14, 2, 12, 1000.0, 0.01)
     assert not q.ctx.rb_table_info(20.0)["used"]
 
 

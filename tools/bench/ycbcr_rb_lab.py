@@ -58,7 +58,8 @@ def main():
     only = args[0] if args and not args[0].startswith("--") else ""
     sweep = "--sweep" in args
     dev = torch.device("cuda:0")
-    ptf, bits, cs, bitsC, mx, mn, sc = L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01, 20.0
+    bits = bitsC = int(os.environ.get("RB_LAB_BITS", "10"))        # RB_LAB_BITS=12: 2 x 64 MiB of tables
+    ptf, cs, mx, mn, sc = L.PTF_PQ, L.CS_YCBCR, 1000.0, 0.01, 20.0
     lut = L.build_lut(ptf, bits, mx, mn)
     ctxs = {}
     variants = {"six_powf": (0, None), "adaptive": (1, None), "always": (2, None)}
