@@ -191,7 +191,13 @@ def _worker8(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "r%d_37.npy" % rank), np.array(d37, dtype=np.int64))
     np.save(os.path.join(out_dir, "r%d_2000.npy" % rank), np.array(d2000, dtype=np.int64))
     np.save(os.path.join(out_dir, "r%d_5.npy" % rank), np.array(d5, dtype=np.int64))
-    np.save(os.path.join(out_dir, "r%d_own.npy" % rank), np.array([len(st.frames), len(mine)], dtype=np.int64))
+    # (4) what bench.py reports as `rccl_ranks_seen` (an all_reduce of ones over the group) and the `config` block every rank
+    # derives from the arguments alone
+    b = _bench_module()
+    sys.argv = ["bench.py", "--gpus", "8", "--stream-frames", "2000"]
+    cfgblk = b.config_block(b.parse(), world)
+    np.save(os.path.join(out_dir, "r%d_own.npy" % rank),
+            np.array([len(st.frames), len(mine), b.ranks_seen(dev), cfgblk["resident_frames_per_rank"][rank]], dtype=np.int64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -212,7 +218,7 @@ def test_eight_rank_gloo_streams_with_uneven_shards(tmp_path):
         assert np.load(tmp_path / ("r%d_37.npy" % r)).tolist() == e37
         assert np.load(tmp_path / ("r%d_2000.npy" % r)).tolist() == e2000
         assert np.load(tmp_path / ("r%d_5.npy" % r)).tolist() == [1000, 1001, 1002, 1003, 1004]
-        assert np.load(tmp_path / ("r%d_own.npy" % r)).tolist() == [5 if r < 5 else 4, 250]
+        assert np.load(tmp_path / ("r%d_own.npy" % r)).tolist() == [5 if r < 5 else 4, 250, 8, 250]
 
 
 def _timer_worker8(rank, world, port, out_dir):
@@ -296,3 +302,49 @@ def test_bench_plan_only_for_eight_gpus():
     rc, d = _plan(["--gpus", "8", "--stream-frames", "37"])
     assert rc == 0 and [p["frames"] for p in d["ranks"]] == [5, 5, 5, 5, 5, 4, 4, 4]
     assert all(p["placement"] == "plain allocations" for p in d["ranks"])
+
+
+def test_plan_is_a_function_of_the_arguments_only():
+    """The launcher form at N = 1 (WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 in the environment) and the plain command line plan the SAME
+    run: `--plan-only` prints identical JSON, and its `config` is what the bench line carries (bench.main takes it from
+    config_block before any process-group, pool or free-memory work).  No free-memory figure enters `config`."""
+    import json
+    import subprocess
+    import sys
+    outs = []
+    for env_extra in ({}, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}):
+        e = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            e.pop(k, None)
+        e.update(env_extra)
+        for free in ("280", "150", "60"):
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--plan-only", "--hbm-free-gb", free],
+                               capture_output=True, text=True, env=e, timeout=120)
+            outs.append((free, json.loads(p.stdout.strip().splitlines()[-1]), p.returncode))
+    cfgs = [json.dumps(d["config"], sort_keys=True) for _, d, _ in outs]
+    assert len(set(cfgs)) == 1                                     # the same configuration whatever the environment or the free HBM
+    c = outs[0][1]["config"]
+    assert c["resident_frames"] == 500 and c["stream_frames"] == 500 and c["frames_per_step"] == 20 and c["scaling"] == "weak"
+    assert "500-frame resident stream" in c["workload"] and c["distinct_input_GB_per_gpu"] == 49.77
+    by_free = {f: (d, rc) for f, d, rc in outs[:3]}
+    assert by_free["280"][0]["ranks"][0]["placement"] == "chunk pool" and by_free["280"][1] == 0
+    # 150 GB free: the pool would not get its chunks -> the SAME 500 frames in plain allocations; 60 GB: does not fit, exit code 1
+    assert by_free["150"][0]["ranks"][0]["placement"] == "plain allocations" and by_free["150"][0]["fits"] and by_free["150"][1] == 0
+    assert not by_free["60"][0]["fits"] and by_free["60"][1] == 1
+    assert outs[0][1] == outs[3][1]                                # launcher environment: identical plan
+
+
+def test_multi_gpu_line_is_self_describing():
+    """`--gpus 8 --stream-frames 2000 --plan-only` (BASELINE configs[4]): 250 frames per rank, strong scaling, and the stream
+    digest the run must reproduce; the weak-scaling default says 500 per rank and 4000 in all"""
+    rc, d = _plan(["--gpus", "8", "--stream-frames", "2000"])
+    assert rc == 0 and d["scaling"] == "strong" and d["expected_stream_digest"] == "54051a63ee9b1773"
+    c = d["config"]
+    assert c["resident_frames_per_rank"] == [250] * 8 and c["resident_frames"] == 250 and c["stream_frames"] == 2000
+    assert c["scaling"] == "strong" and c["expected_stream_digest"] == "54051a63ee9b1773"
+    rc, d = _plan(["--gpus", "8"])
+    c = d["config"]
+    assert d["scaling"] == "weak" and c["resident_frames_per_rank"] == [500] * 8 and c["stream_frames"] == 4000
+    assert d["expected_stream_digest"] is None
+    rc, d = _plan(["--gpus", "8", "--stream-frames", "37"])       # no known digest for other streams
+    assert d["config"]["resident_frames_per_rank"] == [5, 5, 5, 5, 5, 4, 4, 4] and d["expected_stream_digest"] is None
