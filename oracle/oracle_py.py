@@ -28,7 +28,7 @@ def build(ref: bool = True) -> None:
     """(Re)build the oracle; the reference build is attempted only where /root/reference exists."""
     targets = ["all"]
     if ref and os.path.isdir("/root/reference/src"):
-        targets += ["ref", "ref_planes", "ref_args"]
+        targets += ["ref", "ref_planes", "ref_args", "ref_full"]
     subprocess.run(["make", "-s", "-C", HERE] + targets, check=True)
 
 

@@ -4,15 +4,13 @@
  * (/root/reference/src/luma_decoder.cpp:205-240), on caller-supplied data.
  * TEST INFRASTRUCTURE ONLY; built only where /root/reference exists (this container), by `make -C oracle ref_planes`.
  *
- * The reference's translation units are compiled unmodified, where they lie, against the public libvpx headers
- * (vpx/*.h, extracted from the vendored lib/libvpx.tar.gz -- they need no configure-generated header) and the vendored
- * libebml / libmatroska sources.  libvpx itself is NOT built (its configure step generates code); the vpx_codec_* /
- * vpx_img_* functions that luma_encoder.cpp / luma_decoder.cpp reference stay unresolved at link time
- * (-Wl,--unresolved-symbols=ignore-all, lazy binding) and are never reached: this harness never calls initialize(),
- * run() or the destructors' codec branches (m_initialized stays false).  Nothing here stands in for a libvpx function:
- * the two plane loops only read / write a vpx_image_t's public data fields (planes, stride, d_w, d_h, chroma shifts,
- * fmt), which the harness fills with the caller's buffers exactly as vpx_img_alloc(fmt, w, h, 32) / the VP9 decoder
- * would describe them.
+ * The reference's translation units are compiled unmodified, where they lie, and linked COMPLETELY (oracle/Makefile,
+ * `ref_planes`): against the vendored libvpx built generic-gnu by its own configure + make, and the vendored libebml /
+ * libmatroska sources.  Nothing is left unresolved and nothing stands in for a libvpx function.  The harness itself never
+ * calls initialize() / run(): the two plane loops only read / write a vpx_image_t's public data fields (planes, stride,
+ * d_w, d_h, chroma shifts, fmt), which it fills with the caller's buffers exactly as vpx_img_alloc(fmt, w, h, 32) / the VP9
+ * decoder would describe them -- so that the loops can be driven with chosen strides, garbage codes and ragged sizes.
+ * (The complete applications, lumaenc / lumadec through VP9 and Matroska, are oracle/_ref/full/lumaenc_ref / lumadec_ref.)
  *
  *   ref_planes_tool enc ptf bits cs bitsC maxLum minLum profile w h s0 s1 s2 xform sc in.f32 out.planes [lut.f32]
  *       in: 3*w*h floats (LumaFrame layout).  xform=1: m_quant.transformColorSpace(frame,true,sc) first, i.e. the body

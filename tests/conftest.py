@@ -15,10 +15,10 @@ def pytest_configure(config):
 # Order of the GPU suite (the driver runs `pytest -x -m gpu`; whatever stops the run must not stand in front of the
 # comparisons with the reference's results): golden-fixture and oracle parity -> BASELINE's full-size configurations ->
 # the other oracle comparisons (placement: two of its tests compare with the oracle) -> exhaustive sweeps -> facade and tools ->
-# TSan -> the bench contract LAST: no comparison with the oracle sits behind a test that starts bench.py.
+# the linked drop-in against the complete reference applications -> TSan -> the bench contract LAST: no comparison with the oracle sits behind a test that starts bench.py.
 # Files not named here keep their alphabetical place between the sweeps and the facade.
 _GPU_ORDER = ["test_gpu_parity.py", "test_gpu_baseline_configs.py", "test_gpu_half_upload.py", "test_gpu_half_table.py",
-              "test_gpu_abi2.py", "test_gpu_placement.py", "test_gpu_exhaustive.py", None, "test_gpu_facade.py", "test_gpu_tsan.py",
+              "test_gpu_abi2.py", "test_gpu_placement.py", "test_gpu_exhaustive.py", None, "test_gpu_facade.py", "test_gpu_dropin.py", "test_gpu_tsan.py",
               "test_gpu_multi.py"]
 
 

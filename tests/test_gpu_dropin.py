@@ -1,0 +1,97 @@
+"""The drop-in LINKED and RUN through the real downstream (VERDICT r05 "missing" 2): the reference's own applications with
+this repo's hot path inside, next to the complete, unmodified reference, on the same inputs.
+
+`make -C oracle ref_full` (build container only: it needs /root/reference) builds the vendored libvpx (generic-gnu, its own
+configure + make), libebml and libmatroska and links, under oracle/_ref/full/:
+    lumaenc_ref / lumadec_ref       the reference's applications as they are (CPU hot loops);
+    lumaenc_hipB / lumadec_hipB     the same sources with tools/integration/apply_patch_b.py applied: the two hot loops
+                                    replaced by C-ABI calls (lumahip_encode_frame_host / lumahip_decode_frame_host) --
+                                    INTEGRATION.md way B;
+    sink_encode_hipA / source_decode_hipA   this repo's LumaEncoder / LumaDecoder facade with the reference's libvpx +
+                                    MkvInterface stages attached by tools/integration/vpx_mkv_{sink,source}.h -- way A.
+The binaries travel to the GPU box prebuilt (oracle/_ref is git-ignored, not gpurun-ignored); nothing here reads
+/root/reference.  What is asserted: the Matroska file the GPU-backed encoder writes is the reference's file byte for byte
+(bit-exact planes in, deterministic VP9 out; the one field that differs between any two runs is the container's DateUTC), and
+the frames the GPU-backed decoder writes from a real VP9 decoder's planes -- lossy codes, decoder-chosen strides -- are the
+reference's frames byte for byte.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = os.path.join(ROOT, "oracle", "_ref", "full")
+TOOLS = ["lumaenc_ref", "lumadec_ref", "lumaenc_hipB", "lumadec_hipB", "sink_encode_hipA", "source_decode_hipA"]
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_tools():
+    missing = [t for t in TOOLS if not os.path.exists(os.path.join(FULL, t))]
+    if missing:
+        pytest.skip("oracle/_ref/full/%s not built (`make -C oracle ref_full` needs /root/reference: build container only)" % missing[0])
+
+
+def run(tool, *args, cwd):
+    r = subprocess.run([os.path.join(FULL, tool)] + list(args), cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "%s %s failed:\n%s" % (tool, " ".join(args), r.stderr[-2000:])
+    return r.stderr
+
+
+def same_mkv(a, b):
+    """byte-identical except the DateUTC element (8 bytes of nanoseconds since 2001, written at mux time: two runs of the SAME
+    binary differ there too)"""
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert len(da) == len(db) and len(da) > 1000, (len(da), len(db))
+    diff = [i for i in range(len(da)) if da[i] != db[i]]
+    assert not diff or (diff[-1] - diff[0] < 8 and diff[0] < 8192), "%d bytes differ, first at %d, last at %d" % (len(diff), diff[0], diff[-1])
+    return len(diff)
+
+
+# (name, lumaenc options, frames): the reference's defaults = BASELINE configs[0]'s recipe; the HDR10 recipe of configs[2];
+# configs[3]'s LOG 12-bit table; 8-bit 4:2:0 and 4:4:4 profiles; lossless (the VP9 stage then carries the planes exactly)
+CASES = [
+    ("default_pq11_luv", [], 3),
+    ("hdr10_ycbcr", ["-cs", "YCBCR", "-pb", "10", "-cb", "10", "-ma", "1000", "-mi", "0.01", "-sc", "20"], 2),
+    ("log12_luv", ["-ptf", "LOG", "-pb", "12"], 2),
+    ("profile0_8bit", ["-p", "0", "-pb", "8", "-eb", "8"], 2),
+    ("profile3_xyz", ["-p", "3", "-cs", "XYZ", "-pb", "12", "-cb", "12"], 1),
+    ("lossless", ["-l"], 2),
+]
+
+
+@pytest.mark.parametrize("name,opts,frames", CASES, ids=[c[0] for c in CASES])
+def test_patched_reference_applications_equal_the_reference(tmp_path, name, opts, frames):
+    """INTEGRATION.md way B end to end: lumaenc / lumadec of the reference with the two hot loops on the MI355X, against the
+    unmodified applications -- same .mkv, same decoded frames"""
+    _need_tools()
+    d = str(tmp_path)
+    common = ["-i", "__test__", "-f", "1:1:%d" % frames] + opts
+    run("lumaenc_ref", *common, "-o", "ref.mkv", cwd=d)
+    err = run("lumaenc_hipB", *common, "-o", "hip.mkv", cwd=d)
+    assert "%d frames encoded" % frames in err
+    same_mkv(os.path.join(d, "ref.mkv"), os.path.join(d, "hip.mkv"))
+    # decode the REFERENCE's file with both decoders
+    run("lumadec_ref", "-i", "ref.mkv", "-o", "ref_%05d.exr", cwd=d)
+    run("lumadec_hipB", "-i", "ref.mkv", "-o", "hip_%05d.exr", cwd=d)
+    for f in range(1, frames + 1):
+        a = open(os.path.join(d, "ref_%05d.exr" % f), "rb").read()
+        b = open(os.path.join(d, "hip_%05d.exr" % f), "rb").read()
+        assert len(a) > 10000 and a == b, "decoded frame %d differs" % f
+    assert not os.path.exists(os.path.join(d, "ref_%05d.exr" % (frames + 1)))
+
+
+def test_facade_with_the_reference_downstream_equals_the_reference(tmp_path):
+    """INTEGRATION.md way A end to end: this repo's LumaEncoder + VpxMkvSink writes the file the reference's lumaenc writes;
+    this repo's LumaDecoder + VpxMkvSource decodes it to the frames the reference's lumadec writes"""
+    _need_tools()
+    d = str(tmp_path)
+    run("lumaenc_ref", "-i", "__test__", "-f", "1:1:3", "-o", "ref.mkv", cwd=d)
+    run("sink_encode_hipA", "a.mkv", "3", cwd=d)
+    same_mkv(os.path.join(d, "ref.mkv"), os.path.join(d, "a.mkv"))
+    run("lumadec_ref", "-i", "ref.mkv", "-o", "ref_%05d.exr", cwd=d)
+    err = run("source_decode_hipA", "ref.mkv", "a_%05d.exr", cwd=d)
+    assert "3 frames decoded" in err
+    for f in (1, 2, 3):
+        assert open(os.path.join(d, "ref_%05d.exr" % f), "rb").read() == open(os.path.join(d, "a_%05d.exr" % f), "rb").read()
