@@ -87,9 +87,10 @@ def test_facade_with_the_reference_downstream_equals_the_reference(tmp_path):
     this repo's LumaDecoder + VpxMkvSource decodes it to the frames the reference's lumadec writes"""
     _need_tools()
     d = str(tmp_path)
+    os.mkdir(os.path.join(d, "a"))
     run("lumaenc_ref", "-i", "__test__", "-f", "1:1:3", "-o", "ref.mkv", cwd=d)
-    run("sink_encode_hipA", "a.mkv", "3", cwd=d)
-    same_mkv(os.path.join(d, "ref.mkv"), os.path.join(d, "a.mkv"))
+    run("sink_encode_hipA", "ref.mkv", "3", cwd=os.path.join(d, "a"))     # (the container records the output file's name)
+    same_mkv(os.path.join(d, "ref.mkv"), os.path.join(d, "a", "ref.mkv"))
     run("lumadec_ref", "-i", "ref.mkv", "-o", "ref_%05d.exr", cwd=d)
     err = run("source_decode_hipA", "ref.mkv", "a_%05d.exr", cwd=d)
     assert "3 frames decoded" in err
