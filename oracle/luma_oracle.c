@@ -628,3 +628,33 @@ uint64_t lo_fnv1a64_rows(const void *data, size_t row_bytes, size_t rows, size_t
         }
     return hsh;
 }
+
+/* src/lumaplay_dequantizer.frag:145-156 (see luma_oracle.h) */
+void lo_display_transform(const float *rgb, size_t n, double exposure, double gamma, int doTmo, int ldrSim,
+                          unsigned char *rgba)
+{
+    size_t i;
+    int c;
+    for (i = 0; i < n; i++) {
+        for (c = 0; c < 3; c++) {
+            double v = (double)rgb[(size_t)c * n + i];
+            if (ldrSim > 0) {                                   /* :145-146 */
+                double f = floor(256.0 * v);
+                f = f < 256.0 ? f : 256.0;                      /* min(vec3(256), .) */
+                f = f > 1.0 ? f : 1.0;                          /* max(vec3(1), .)   */
+                v = exposure * f / 256.0;
+            } else {
+                v = v * exposure;                               /* :148 */
+            }
+            if (doTmo > 0) {                                    /* :150-154 */
+                const double nn = 0.8, sig = 0.8;
+                const double vn = pow(v > 0.0 ? v : 0.0, nn);
+                v = vn / (vn + pow(sig, nn));
+            }
+            v = pow(v > 0.0 ? v : 0.0, 1.0 / gamma);            /* :156 */
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);            /* the 8-bit colour buffer's clamp ... */
+            rgba[4 * i + c] = (unsigned char)floor(255.0 * v + 0.5);   /* ... and conversion */
+        }
+        rgba[4 * i + 3] = 255;
+    }
+}

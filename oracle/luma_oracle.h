@@ -93,6 +93,18 @@ void lo_decode_frame_mt(const lo_quantizer *q, const unsigned char *const planes
  * (The reference calls libm powf, src/luma_quantizer.cpp:485-501.) */
 size_t lo_powf_compare(const float *got, uint32_t first, size_t n, float y, int nthreads, uint32_t *first_bad);
 
+/* The player's display-side transform, src/lumaplay_dequantizer.frag:145-156, on ALREADY DECODED linear RGB (the fragment's
+ * `RGB` divided by `scaling`, which LumaDecoder::decode has applied), evaluated in binary64:
+ *   ldrSim:  v = exposure * max(1, min(256, floor(256 v))) / 256      else  v = v * exposure
+ *   doTmo:   v = v^0.8 / (v^0.8 + 0.8^0.8)
+ *   out    = v^(1/gamma), clamped to [0, 1] and converted as an 8-bit UNORM colour buffer converts gl_FragColor:
+ *            floor(255 v + 0.5); alpha 255.
+ * rgb: planar, 3 planes of n floats; rgba: n x 4 bytes, interleaved.  pow of a negative base (GLSL: undefined) is taken of
+ * max(v, 0).  The reference reads its table through a GL_LINEAR-filtered texture, so it does not pin these bytes; this
+ * restatement is the checker of the fused decode + display kernel (tolerance +-1 code, tests/test_gpu_parity.py). */
+void lo_display_transform(const float *rgb, size_t n, double exposure, double gamma, int doTmo, int ldrSim,
+                          unsigned char *rgba);
+
 /* ExrInterface::testFrame pattern, src/exr_interface.cpp:50-70 */
 void lo_test_frame(float *buf, unsigned w, unsigned h);
 

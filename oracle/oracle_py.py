@@ -78,6 +78,7 @@ def lib():
         L.lo_splitmix64.argtypes = [C.c_uint64]
         L.lo_splitmix64.restype = C.c_uint64
         L.lo_synth_frame.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64]
+        L.lo_display_transform.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
         L.lo_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
         L.lo_fnv1a64.restype = C.c_uint64
         L.lo_fnv1a64_basis.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
@@ -225,6 +226,15 @@ def test_frame(w=1280, h=720) -> np.ndarray:
 def synth_frame(w, h, seed=20250929, frame=0) -> np.ndarray:
     out = np.empty((3, h, w), dtype=np.float32)
     lib().lo_synth_frame(out.ctypes.data, w, h, seed, frame)
+    return out
+
+
+def display_transform(rgb: np.ndarray, exposure=1.0, gamma=2.2, do_tmo=0, ldr_sim=0) -> np.ndarray:
+    """the player's display transform (src/lumaplay_dequantizer.frag:145-156) on decoded linear RGB (3, h, w) -> RGBA8 (h, w, 4)"""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    _, h, w = rgb.shape
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    lib().lo_display_transform(rgb.ctypes.data, h * w, float(exposure), float(gamma), int(do_tmo), int(ldr_sim), out.ctypes.data)
     return out
 
 

@@ -119,3 +119,37 @@ def test_testframe_plane_digests(oracle_mod, w, h, d):
     f2 = o.test_frame(w, h)
     planes2, _, _ = qq.encode(f2, 1.0, 2, threads=4)
     assert all(np.array_equal(a, b) for a, b in zip(planes, planes2))
+
+
+def test_display_transform_restates_the_players_fragment(oracle_mod):
+    """oracle/luma_oracle.c lo_display_transform against src/lumaplay_dequantizer.frag:145-156 worked by hand (binary64):
+    plain exposure + gamma; the LDR simulation's floor / clamp to [1, 256] / 256; the sigmoid tone curve; the 8-bit colour
+    buffer's clamp and round-to-nearest; alpha 255; negative inputs (pow of a negative base is undefined in GLSL: taken of 0)."""
+    o = oracle_mod
+    v = np.array([0.0, 0.001, 0.18, 0.5, 1.0, 2.0, -0.25, 100.0], dtype=np.float32)
+    rgb = np.stack([v, v * np.float32(0.5), v * np.float32(2.0)]).reshape(3, 1, v.size)
+    x = rgb.astype(np.float64)
+
+    def code(t):
+        return np.floor(255.0 * np.clip(t, 0.0, 1.0) + 0.5).astype(np.int32)
+
+    # (1) exposure 1.5, gamma 2.2
+    got = o.display_transform(rgb, 1.5, 2.2, 0, 0)
+    assert got.shape == (1, v.size, 4) and np.all(got[..., 3] == 255)
+    exp = code(np.maximum(x * 1.5, 0.0) ** (1.0 / 2.2))
+    assert np.array_equal(got[0, :, :3].T.astype(np.int32), exp[:, 0, :])
+    assert got[0, 0, 0] == 0 and got[0, 7, 0] == 255 and got[0, 6, 1] == 0            # black, saturated, negative
+    assert got[0, 2, 0] == int(np.floor(255.0 * (0.18 * 1.5) ** (1 / 2.2) + 0.5))    # 0.18 grey under +0.58 stops
+    # (2) LDR simulation: 256 levels, never below level 1, never above 256
+    got = o.display_transform(rgb, 1.0, 1.8, 0, 1)
+    lv = np.clip(np.floor(256.0 * x), 1.0, 256.0) / 256.0
+    assert np.array_equal(got[0, :, :3].T.astype(np.int32), code(lv ** (1.0 / 1.8))[:, 0, :])
+    assert got[0, 0, 0] == int(np.floor(255.0 * (1.0 / 256.0) ** (1 / 1.8) + 0.5))   # black is level 1, not 0
+    # (3) tone curve v^0.8 / (v^0.8 + 0.8^0.8), then gamma 2.4, with exposure 4
+    got = o.display_transform(rgb, 4.0, 2.4, 1, 0)
+    vn = np.maximum(x * 4.0, 0.0) ** 0.8
+    assert np.array_equal(got[0, :, :3].T.astype(np.int32), code((vn / (vn + 0.8 ** 0.8)) ** (1.0 / 2.4))[:, 0, :])
+    # (4) both, the order of the fragment: LDR levels first, tone curve second
+    got = o.display_transform(rgb, 2.0, 2.2, 1, 1)
+    vn = (2.0 * lv) ** 0.8
+    assert np.array_equal(got[0, :, :3].T.astype(np.int32), code((vn / (vn + 0.8 ** 0.8)) ** (1.0 / 2.2))[:, 0, :])
