@@ -252,6 +252,13 @@ int lumahip_quantize_array_host(lumahip_ctx *ctx, const float *in, float *out, s
 int lumahip_dequantize_array_host(lumahip_ctx *ctx, const float *in, float *out, size_t n, unsigned ch);
 
 /* ---- device entry points (batched, asynchronous on the context's stream) ----------------------- */
+/* "Asynchronous" has one exception.  YCbCr streams choose between two kernels per launch from what earlier launches reported
+ * about the data (binary16-valued inputs on the encode side, locality of the codes on the decode side): a call may then WAIT,
+ * on the host, for the eligible launch issued four such launches earlier -- never for more recent ones, so up to three launches
+ * stay queued and the device does not run dry.  The wait is an event wait, not a poll, so that which kernel runs is a function
+ * of the data alone.  lumahip_tune(ctx, "half_table", 0 or 2) / ("ycbcr_rb_tables", 0 or 2) fix the choice and remove
+ * the wait; other colour spaces never wait.  The red / blue tables of the YCbCr decode kernels are optional: when their memory
+ * (8 MiB for the HDR10 recipe, up to 2 x 128 MiB) cannot be had, the call proceeds on the plain kernels. */
 
 /* nframes frames, frame f at rgb_dev + f*frame_stride floats (LumaFrame layout each); plane p of frame f
  * at planes_dev[p] + f*plane_frame_stride[p] bytes.  stats_dev (nullable) receives per frame

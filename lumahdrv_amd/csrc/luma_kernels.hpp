@@ -976,6 +976,10 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     // once the round-4 changes had cut its VALU work by 13 %: 3.3 % slower, 1.296 against 1.253 ms per 20 x 4K, same box.)
     using DecTab = PowfTablesWide;
     constexpr int WHAT = (GL ? 0 : STAGE_LUT) | (CS == CS_YCBCR ? STAGE_POWF : 0) | (UVTAB ? STAGE_UV : 0) | (YT ? STAGE_YT | STAGE_CT : 0);
+    __shared__ int s_gathered[1];
+    if (RB && threadIdx.x == 0)
+        s_gathered[0] = 0;   // (before the barrier inside stage_tables: no wave can report ahead of the reset; the one reader
+                             //  waits at the barrier at the end)
     stage_tables<WHAT>(smem, a.q);
     const float *s_lut = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>());
     const float *s_uv = reinterpret_cast<const float *>(smem + lds_table_offset<WHAT>() + lds_lut_bytes(a.q));
@@ -985,9 +989,6 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     const int NW = blockDim.x >> 6;
     const int G = gridDim.x;
 
-    __shared__ int s_gathered[RB ? 1 : 1];
-    if (RB && threadIdx.x == 0)
-        s_gathered[0] = 0;   // (stage_tables has synchronised already; the one reader waits at the barrier at the end)
     bool any_gather = false;
     DecUnit<SUB, VW> cur, nxt;
     dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);

@@ -272,6 +272,8 @@ extern "C" int lumahip_tune(lumahip_ctx *c, const char *key, long v)
             return fail(c, LUMAHIP_ERR_ARG, "ycbcr_rb_tables must be 0 (six powf per pixel), 1 (red and blue from the per-stream tables where a wave's codes are close) or 2 (always)");
         c->rb_mode = (int)v;
         lag_policy_reset(c->rb_pol);
+    } else if (k == "test_fail_rb_alloc") {   // tests: the next allocation of the red / blue tables behaves as if hipMalloc had failed
+        c->test_fail_rb_alloc = v != 0;
     } else if (k == "dec_vw") {
         c->dec_vw = v == 2 ? 2 : 0;
     } else if (k == "rb_near_y") {
@@ -430,6 +432,7 @@ static int upload_table(lumahip_ctx *c)
     for (auto &t : c->rb_tabs)     // (the red / blue tables of the YCbCr decode kernels were built from the old y table)
         (void)hipFree(t.d);
     c->rb_tabs.clear();
+    c->rb_unavailable = false;
     c->tix_y.reset();
     HIPCHK(c, hipMalloc(&c->d_lut, lut_floats * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->d_lut, padded.data(), lut_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -945,6 +948,22 @@ bool lag_policy_next(LagPolicy &p, uint32_t **flag)
     p.pending.push_back({e, slot, probe});
     *flag = &p.h_flag[slot];
     return true;
+}
+
+// the launch that was handed the newest word never happened (an error return between lag_policy_next and the kernel launch): no
+// event will be recorded for it and its word stays 0 -- which for the red / blue policy would read as bad news.  Take the entry
+// back; the eligible-launch count keeps the attempt (it only spaces the reads), a probe that did not happen is asked for again.
+void lag_policy_cancel(LagPolicy &p)
+{
+    if (p.pending.empty())
+        return;
+    const LagPolicy::Pending q = p.pending.back();
+    p.pending.pop_back();
+    p.seq--;
+    if (q.probe && p.state == LagPolicy::PROBE_WAIT) {
+        p.state = LagPolicy::BACKOFF;   // backoff == 0: the next eligible launch is the probe
+        p.backoff = 0;
+    }
 }
 
 // right behind a fast launch that was given a feedback word: the event that says its word is final

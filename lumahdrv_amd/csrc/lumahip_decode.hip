@@ -145,7 +145,10 @@ int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
 {
     *tab = nullptr;
     const size_t n = (size_t)c->q.lut_len, nc = (size_t)c->q.maxC + 1;
-    if (c->rb_mode == 0 || !c->q.ytab || 2 * n * nc * sizeof(float) > RB_MAX_BYTES || !(sc == sc))
+    // The tables are a speed-up, never a requirement: when they cannot be had (no memory for them on a nearly full GPU, or the
+    // build launch fails) the call goes on with the plain kernels, and the stream does not ask again (lumahip_set_quantizer
+    // clears `rb_unavailable` with the tables).
+    if (c->rb_mode == 0 || c->rb_unavailable || !c->q.ytab || 2 * n * nc * sizeof(float) > RB_MAX_BYTES || !(sc == sc))
         return LUMAHIP_OK;
     for (auto &t : c->rb_tabs)
         if (memcmp(&t.sc, &sc, 4) == 0) {
@@ -162,7 +165,12 @@ int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
     lumahip_ctx::RbTab t;
     t.sc = sc;
     t.last_use = ++c->rb_clock;
-    HIPCHK(c, hipMalloc(&t.d, 2 * n * nc * sizeof(float)));
+    if (c->test_fail_rb_alloc || hipMalloc(&t.d, 2 * n * nc * sizeof(float)) != hipSuccess) {
+        c->test_fail_rb_alloc = false;
+        (void)hipGetLastError();
+        c->rb_unavailable = true;
+        return LUMAHIP_OK;
+    }
     RbArgs a{};
     a.ytab = c->q.ytab;
     a.out = t.d;
@@ -174,8 +182,10 @@ int rb_table_for(lumahip_ctx *c, float sc, const float **tab)
     hipLaunchKernelGGL(k_build_rb, dim3((unsigned)c->num_cu * 8), dim3(256), 0, c->stream, a);
     // done when this returns, whatever stream or lane the decode launch goes to
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipGetLastError();
         (void)hipFree(t.d);
-        return fail(c, LUMAHIP_ERR_HIP, "building the red / blue tables failed");
+        c->rb_unavailable = true;
+        return LUMAHIP_OK;
     }
     c->rb_tabs.push_back(t);
     *tab = t.d;
@@ -193,13 +203,27 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
             return fail(c, LUMAHIP_ERR_ARG, "null argument");
         if (frame_stride < (size_t)3 * w * h)
             return fail(c, LUMAHIP_ERR_ARG, "frame stride %zu < 3*w*h = %zu floats (packed frames)", frame_stride, (size_t)3 * w * h);
+        // every buffer is written with the vector stores the launch picks from buffer 0's alignment: hold all three to it
+        // (16 bytes where four pixels per thread are possible, 8 always)
         for (int k = 0; k < 3; k++) {
-            if (!is_aligned(rot[k], 16) && ((w % 4) == 0))
-                return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must be 16-byte aligned");
+            if (!is_aligned(rot[k], ((w % 4) == 0 && (frame_stride % 4) == 0) ? 16 : 8))
+                return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must be %d-byte aligned", ((w % 4) == 0 && (frame_stride % 4) == 0) ? 16 : 8);
             rot_planes[k] = rot[0] + (size_t)k * w * h;
         }
         if (rot[0] == rot[1] || rot[1] == rot[2] || rot[0] == rot[2])
             return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must be distinct");
+        // buffer k holds frames k, k + 3, ...: ceil((nframes - k) / 3) frames, the last one 3*w*h floats long
+        for (int i = 0; i < 3; i++)
+            for (int j = i + 1; j < 3; j++) {
+                const size_t ni = (nframes + 2 - (unsigned)i) / 3, nj = (nframes + 2 - (unsigned)j) / 3;
+                if (ni == 0 || nj == 0)
+                    continue;
+                const uintptr_t bi = (uintptr_t)rot[i], bj = (uintptr_t)rot[j];
+                const size_t ei = ((ni - 1) * frame_stride + (size_t)3 * w * h) * sizeof(float);
+                const size_t ej = ((nj - 1) * frame_stride + (size_t)3 * w * h) * sizeof(float);
+                if (bi < bj + ej && bj < bi + ei)
+                    return fail(c, LUMAHIP_ERR_ARG, "the three frame buffers must not overlap (buffers %d and %d do over this batch)", i, j);
+            }
     }
     float *const *rgb = rot ? rot_planes : rgb_in;
     const bool have_rgb = rgb && rgb[0];
@@ -282,6 +306,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     if (rb)
         c->rb_launches++;
     dec_kernel_t kern = pick_dec(cs_eff, sub, vw, gl, dp.rgba != nullptr, yt, rb != nullptr);
+    LagLaunchGuard rb_guard{c->rb_pol, rb_flag};   // (a return before the launch takes the word back: the policy must not wait for it)
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // few_writers: the 4:2:0 16-bit kernels of the HBM-bound colour spaces (12 of 15 bytes per pixel are writes); 2 when the three
@@ -293,6 +318,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     const int grid = grid_for(c, threads, a.g.totalTiles, 1, few_writers, cs_eff == CS_YCBCR);
     hipStream_t s = launch_stream(c, lanes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
+    rb_guard.launched = true;
     if (rb_flag && (rc = lag_policy_launched(c, c->rb_pol, s)))
         return rc;
     HIPCHK(c, hipGetLastError());

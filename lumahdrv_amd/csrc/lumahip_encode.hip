@@ -156,6 +156,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         if (half && c->half_mode == 1 && !lag_policy_next(c->half_pol, &half_flag))   // (mode 2: always, no feedback)
             half = nullptr;
     }
+    LagLaunchGuard half_guard{c->half_pol, half_flag};   // (a return before the launch takes the word back)
     EncArgs a{};
     a.q = ycode ? c->q_y : c->q;
     a.half = half;
@@ -212,6 +213,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
         hipLaunchKernelGGL(k_init_stats, dim3((np + 255) / 256), dim3(256), 0, s, c->d_stats_part, np);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a);
+    half_guard.launched = true;
     if (half_flag && (rc = lag_policy_launched(c, c->half_pol, s)))
         return rc;
     if (stats)

@@ -117,6 +117,8 @@ struct lumahip_ctx {
     };
     std::vector<RbTab> rb_tabs;
     unsigned long rb_clock = 0, rb_launches = 0;
+    bool test_fail_rb_alloc = false;
+    bool rb_unavailable = false;  // allocating or building the tables failed for this stream: plain kernels, no retry per launch
     LagPolicy rb_pol{false, 64};      // which kernel an eligible YCbCr decode launch takes (rb_mode 1): NO report = "no wave found its codes local"
     int rb_mode = 1;              // lumahip_tune("ycbcr_rb_tables"): 0 = six powf per pixel (rounds 3-4), 1 = red / blue from the tables where a
                                   // wave's codes are close to each other (luma_kernels.hpp rb_wave_near), 2 = from the tables always
@@ -276,8 +278,24 @@ int half_table_for(lumahip_ctx *c, float sc, const float **tab);   // *tab = the
 // this eligible launch: the data-dependent ("fast") kernel (true) or the plain one.  On true, *flag is the launch's feedback
 // word (nullptr when the feedback ring could not be set up: the policy then always answers true) and the caller calls
 // lag_policy_launched(c, p, stream) right behind the kernel launch.
+// lag_policy_next may BLOCK the calling thread: it reads the word of the fast launch issued LAG eligible launches earlier after
+// waiting for that launch's event (hipEventSynchronize, not a poll: what the policy decides must be a function of the data, never
+// of how far the device has got).  At most LAG - 1 eligible launches of a context are therefore queued behind the one being
+// waited for -- 3 x 0.4 ms of work at 20 4K frames per launch, 3 x 21 us at one frame against a 6 us launch cost: the device
+// does not run dry; include/lumahip.h says so at the *_device entry points.
 bool lag_policy_next(LagPolicy &p, uint32_t **flag);
 int lag_policy_launched(lumahip_ctx *c, LagPolicy &p, hipStream_t s);
+void lag_policy_cancel(LagPolicy &p);   // the launch lag_policy_next handed a word to did not happen: forget its pending entry
+struct LagLaunchGuard {                 // cancels on every return between lag_policy_next and the kernel launch
+    LagPolicy &p;
+    uint32_t *flag;
+    bool launched = false;
+    ~LagLaunchGuard()
+    {
+        if (flag && !launched)
+            lag_policy_cancel(p);
+    }
+};
 void lag_policy_reset(LagPolicy &p);      // a new stream: waits for the launches in flight, clears their words, state ON_FAST
 void lag_policy_destroy(LagPolicy &p);
 void numa_resolve(lumahip_ctx *c);                                 // fills numa_node / numa_cpus once (cheap afterwards)

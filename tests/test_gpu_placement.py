@@ -174,5 +174,26 @@ def test_packed_frames_rotating_over_three_buffers_equal_the_packed_batch(oracle
             assert np.array_equal(bufs[0][:n3].cpu().numpy().view(np.uint32), exp.reshape(-1).view(np.uint32))
         with pytest.raises(L.LumaHipError):                           # one buffer twice
             ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, [bufs[0].data_ptr(), bufs[0].data_ptr(), bufs[2].data_ptr()], n3)
+        # buffers whose extents over the batch overlap, and a second / third buffer the vector stores cannot take: rejected, nothing written
+        w, h, profile, B = 258, 34, 2, 7                              # (two pixels per thread: 8-byte stores)
+        n3 = 3 * w * h
+        _, hs, st, _ = L.plane_geometry(w, h, profile)
+        psz = [hs[p] * st[p] for p in range(3)]
+        planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+        pl = [p.data_ptr() for p in planes]
+        big = torch.full((12 * n3,), float("nan"), dtype=torch.float32, device=dev)
+        base = big.data_ptr()
+        ok = [base, base + 3 * n3 * 4, base + 6 * n3 * 4]             # three frames each: exactly what B = 7 needs of buffer 0
+        ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, ok, n3)
+        torch.cuda.synchronize()
+        big.fill_(float("nan"))
+        for bad in ([base, base + 2 * n3 * 4, base + 6 * n3 * 4],     # buffer 1 starts inside buffer 0's third frame
+                    [base, base + 3 * n3 * 4, base + 4 * n3 * 4 + 8], # buffer 2 inside buffer 1
+                    [base, base + 3 * n3 * 4 + 4, base + 6 * n3 * 4], # buffer 1 only 4-byte aligned
+                    [base, base + 3 * n3 * 4, base + 6 * n3 * 4 + 4]):
+            with pytest.raises(L.LumaHipError):
+                ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, bad, n3)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(big).all())
         ctx.set_stream(None)
         ctx.close()

@@ -114,6 +114,32 @@ def test_tables_follow_the_quantizer_and_the_prescaling(oracle_mod):
     assert not q.ctx.rb_table_info(20.0)["used"]
 
 
+def test_no_memory_for_the_tables_means_the_plain_kernels_not_an_error(oracle_mod):
+    """the tables are a speed-up, not a requirement: when their allocation fails the decode call goes on with six powf
+    per pixel -- same floats --, lumahip_rb_table_info reports "not used" instead of failing, the stream does not ask again, and
+    the next lumahip_set_quantizer starts afresh"""
+    import lumahdrv_amd as L
+    o = oracle_mod
+    rng = np.random.default_rng(8)
+    y, cb, cr = _picture_codes(rng, 64, 256, True)
+    planes, st = _planes_from_codes(L, y, cb, cr, 2)
+    orc = o.Oracle(*CFG)
+    exp = orc.decode(planes, st, 256, 64, 20.0, 2)
+    q = L.LumaQuantizer()
+    q.setQuantizer(*CFG)
+    q.ctx.tune("test_fail_rb_alloc", 1)                     # the next hipMalloc of the tables "fails"
+    got = q.ctx.decode_frame(planes, st, 256, 64, 20.0, 2)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    info = q.ctx.rb_table_info(20.0)
+    assert not info["used"] and info["table_launches"] == 0
+    got = q.ctx.decode_frame(planes, st, 256, 64, 20.0, 2)  # no retry per launch
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)) and q.ctx.rb_table_info(20.0)["table_launches"] == 0
+    q.setQuantizer(*CFG)                                    # a new stream asks again
+    got = q.ctx.decode_frame(planes, st, 256, 64, 20.0, 2)
+    info = q.ctx.rb_table_info(20.0)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)) and info["used"] and info["table_launches"] == 1
+
+
 def test_streams_of_unrelated_pixels_back_off_to_the_plain_kernels(oracle_mod):
     """mode 1: a launch none of whose waves found its codes local leaves its feedback word clear; the host reads launch j's word
     when it issues eligible launch j + 4 (after j's completion event) and sends 16 launches to the kernels without the test, then
