@@ -56,7 +56,7 @@ import torch.distributed as dist  # noqa: E402
 from lumahdrv_amd.benchlib.legs import load_profile, run_workload  # noqa: E402,F401
 from lumahdrv_amd.benchlib.plan import (H4K, OTHER_WORKLOADS, SEED, W4K, config_block, plan_only, pool_request,  # noqa: E402,F401
                                         stream_shard_plan)
-from lumahdrv_amd.benchlib.resident import StreamDoesNotFit, make_pool  # noqa: E402
+from lumahdrv_amd.benchlib.resident import StreamDoesNotFit, make_pool, make_small_pool  # noqa: E402
 from lumahdrv_amd.benchlib.stream import frame_digests, run_stream, run_stream_multi  # noqa: E402,F401
 from lumahdrv_amd.benchlib.timing import Timer, ranks_seen  # noqa: E402,F401
 
@@ -329,6 +329,8 @@ def run_default(L, args, config, rank, n_gpus, local_rank, use_dist, dev, sha):
         ro, _ = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha, None,
                              legs="encode")
         res["value_placement_off"] = ro["value"]
+        res["placement_off"] = {"value": ro["value"], "value_ordered": ro.get("value_ordered"), "frac_ordered": ro.get("frac_ordered"),
+                                "resident_frames": ro["resident_frames"]}
     # ---- the other single-GPU configurations of BASELINE.json, same run, each with its own roofline (N = 1 only)
     if n_gpus == 1 and not args.no_other_workloads and args.workload == "pq11_luv" and (w, h) == (W4K, H4K):
         others = {}
@@ -338,6 +340,18 @@ def run_default(L, args, config, rank, n_gpus, local_rank, use_dist, dev, sha):
         res["other_workloads"] = others
     if pool is not None:
         pool.close()
+    if args.placement == "auto" and args.workload == "pq11_luv" and not args.no_placement_off and (w, h) == (W4K, H4K):
+        # ... and what a caller gets that keeps a FEW GB resident and shares the GPU: lumahip_pool_create_small (a dozen chunks probed
+        # for milliseconds, 2 float + 1 Y + 1 U/V chunks = 8 GB kept), a 2-batch resident stream (4 GB of input >> the 256 MB MALL)
+        sp = make_small_pool(L, dev, local_rank)
+        if sp is not None:
+            rsm, _ = run_workload(L, args, args.workload, w, h, B, K, Wm, rank, n_gpus, local_rank, use_dist, dev, False, sha, sp,
+                                  legs="encode", nbatch=2)
+            res["value_small_pool"] = rsm["value"]
+            res["small_pool"] = dict({"value": rsm["value"], "value_ordered": rsm.get("value_ordered"), "frac_ordered": rsm.get("frac_ordered"),
+                                      "resident_frames": rsm["resident_frames"], "resident_stream": rsm["resident_stream"],
+                                      "pool_GB_kept": round(4 * sp.pool.chunk_bytes / 1e9, 1)}, **sp.stats)
+            sp.close()
     if hostfed is not None:
         res["facade_hostfed"] = hostfed
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,7 @@ extern "C" {
 
 /* ABI history.  The BINARY interface has only ever grown: every symbol of an earlier version is still exported with the same
  * signature, so a program linked against version 2 runs against this library.
+ *   5 (round 6): addition -- lumahip_pool_create_small.
  *   4 (round 5): additions -- lumahip_rb_table_info, lumahip_lin_index_host, LUMAHIP_POOL_ROTATING, the lumahip_tune keys
  *     "ycbcr_rb_tables" / "rb_near_y" / "rb_near_c" / "lin_index"; lumahip_quantizer_info may answer search mode 7.  Behaviour:
  *     the half-input table's kernel choice is now a function of the stream's data only (feedback read four eligible launches
@@ -50,7 +51,7 @@ extern "C" {
  *     lumahip_time_launches returns LUMAHIP_ERR_STATE inside an unordered section, the default of lumahip_tune("copy_threads")
  *     went from 3 to 5, and lumahip_multi_* with every shard on one device takes the table from the host instead of RCCL
  *     (lumahip_multi_set_transport(m, 1) restores the broadcast). */
-#define LUMAHIP_ABI_VERSION 4
+#define LUMAHIP_ABI_VERSION 5
 
 enum lumahip_status {
     LUMAHIP_OK = 0,
@@ -405,6 +406,12 @@ typedef struct lumahip_pool_config {
     int probe_iters;         /* launches per probe (0 = 2) */
 } lumahip_pool_config;
 int lumahip_pool_create(lumahip_ctx *ctx, const lumahip_pool_config *cfg, lumahip_pool **out);
+/* The SMALL pool: for a caller that keeps a few GB of frames on the device and shares the GPU.  Takes max(8, chunks wanted + 4)
+ * chunks for a few tens of milliseconds instead of all free memory for seconds, finds the region groups among them (one retry with
+ * twice as many when the first attempt sees a single group), keeps the chunks wanted and returns the rest.  Same object, same
+ * calls as above afterwards.  A 40-frame 4K stream in 2 float + 1 Y + 1 U/V chunks (8 GB): 0.73 of the roofline for one launch at
+ * a time against 0.67 in plain allocations (profiles/r06_small_pool.txt; bench.py value_small_pool). */
+int lumahip_pool_create_small(lumahip_ctx *ctx, int n_float, int n_y, int n_uv, int n_striped, lumahip_pool **out);
 void lumahip_pool_destroy(lumahip_pool *pool);   /* frees every chunk, handed out or not */
 /* One whole chunk of `kind` (fastest first).  group: -1 = any; for LUMAHIP_POOL_STRIPED the region group (0, 1, 2) the chunk
  * must come from.  LUMAHIP_ERR_STATE when none is left.

@@ -28,9 +28,10 @@ def load_profile(path, workload, px_step, sha):
     return None
 
 
-def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha, pool=None, legs="full"):
+def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dist, dev, main, sha, pool=None, legs="full", nbatch=None):
     """one workload: resident synthetic stream, encode timed (plus decode / round trip for the main one), roofline blocks.
-    legs: "full" = every leg; "encode" = the encode leg only (the placement-off comparison)."""
+    legs: "full" = every leg; "encode" = the encode leg only, two lanes and ordered (the placement-off and small-pool comparisons).
+    nbatch: batches of the resident stream when it is not the plan's (the small-pool leg: 2)."""
     from lumahdrv_amd.sharding import broadcast_quantizer
     ptf, bits, cs, bitsC, maxLum, minLum, sc, profile, desc, xf_desc, kname = WORKLOADS[name]
     cfg0 = lut0 = None
@@ -48,7 +49,8 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
     _, hs, st, _ = L.plane_geometry(w, h, profile)
     psz = [hs[p] * st[p] for p in range(3)]
     # the stream is the PLAN's (benchlib/plan.py: a function of the arguments); the pool only decides where its batches live
-    nbatch = resident_frames(w, h, B, main) // B
+    if nbatch is None:
+        nbatch = resident_frames(w, h, B, main) // B
     rs = ResidentStream(dev, w, h, B, nbatch, psz, pool, want_output=(legs == "full"),
                         striped_ok=(legs == "full" and args.decode_layout == "auto"), allow_short=args.allow_short_stream)
     nbatch, ptrs, striped, out_fs = rs.nbatch, rs.ptrs, rs.striped, rs.out_fs     # (nbatch is smaller only with --allow-short-stream)
@@ -87,6 +89,9 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
          "frames_per_step": B, "width": w, "height": h, "preScaling": sc, "profile": profile,
          "distinct_input_GB_per_gpu": round(nfr * n3 * 4 / 1e9, 2)}
     if legs == "encode":
+        if lanes:
+            r["value_ordered"] = round(rate(tm.run(enc, lanes=0)["wall_median"]), 1)   # the same launches back to back on one stream
+            r["frac_ordered"] = round(BYTES_PER_PIXEL * r["value_ordered"] * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)
         ctx.close()
         rs.close()
         return r, cfg

@@ -18,6 +18,24 @@ class StreamDoesNotFit(RuntimeError):
     pass
 
 
+def make_small_pool(L, dev, local_rank, n_float=2, n_y=1, n_uv=1):
+    """lumahip_pool_create_small: a few chunks for a caller that keeps a few GB resident and shares the GPU (None: not available)"""
+    try:
+        from lumahdrv_amd.placement import HbmChunkPool
+        ctx = L.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_quantizer(L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005, L.build_lut(L.PTF_PQ, 11, 1e4, 0.005))
+        pool = HbmChunkPool(ctx, dev, n_float, n_y, n_uv, 0, small=True)
+        ctx.close()
+        if len(pool.float) >= n_float and pool.y and pool.uv:
+            return pool
+        pool.close()
+    except Exception as e:
+        sys.stderr.write("bench.py: small chunk pool unavailable (%r)\n" % (e,))
+        torch.cuda.empty_cache()
+    return None
+
+
 def make_pool(L, args, dev, local_rank, w, h, B, nbatches=None, with_output=True):
     """--placement auto: the chunk pool (C ABI lumahip_pool_*) the resident streams are carved from (None: plain allocations)"""
     if args.placement != "auto":
@@ -151,4 +169,4 @@ class ResidentStream:
         torch.cuda.empty_cache()
 
 
-__all__ = ["ResidentStream", "StreamDoesNotFit", "make_pool", "PACKED_RING"]
+__all__ = ["ResidentStream", "StreamDoesNotFit", "make_pool", "make_small_pool", "PACKED_RING"]

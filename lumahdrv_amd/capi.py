@@ -29,7 +29,7 @@ SYMBOLS = [
     "lumahip_decode_frames_device", "lumahip_decode_frames_device_rotating", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
     "lumahip_device", "lumahip_encode_frames_device_planar", "lumahip_decode_frames_device_planar", "lumahip_begin_unordered", "lumahip_end_unordered",
     "lumahip_probe_decode_traffic_device",
-    "lumahip_pool_create", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
+    "lumahip_pool_create", "lumahip_pool_create_small", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
     "lumahip_pool_stats_json", "lumahip_pool_find_groups",
     "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl", "lumahip_multi_set_transport", "lumahip_multi_transport_note",
     "lumahip_shard_range", "lumahip_multi_set_quantizer", "lumahip_multi_encode_frames_host", "lumahip_multi_decode_frames_host",
@@ -169,6 +169,7 @@ def lib():
     L.lumahip_end_unordered.argtypes = [vp]
     L.lumahip_probe_decode_traffic_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, pp3, sz, i, C.POINTER(f)]
     L.lumahip_pool_create.argtypes = [vp, C.POINTER(PoolConfig), C.POINTER(vp)]
+    L.lumahip_pool_create_small.argtypes = [vp, i, i, i, i, C.POINTER(vp)]
     L.lumahip_pool_destroy.argtypes = [vp]
     L.lumahip_pool_destroy.restype = None
     L.lumahip_pool_alloc.argtypes = [vp, i, i, C.POINTER(vp)]
@@ -669,11 +670,14 @@ class Context:
 class Pool:
     """lumahip_pool: device memory in chunks, classified by HBM region group (include/lumahip.h)"""
 
-    def __init__(self, ctx: Context, n_float, n_y, n_uv, n_striped=0, chunk_bytes=0, keep_free=0, max_chunks=0, iters=0):
+    def __init__(self, ctx: Context, n_float, n_y, n_uv, n_striped=0, chunk_bytes=0, keep_free=0, max_chunks=0, iters=0, small=False):
         self.L = lib()
-        cfg = PoolConfig(chunk_bytes, n_float, n_y, n_uv, n_striped, keep_free, max_chunks, iters)
         h = C.c_void_p()
-        rc = self.L.lumahip_pool_create(ctx.h, C.byref(cfg), C.byref(h))
+        if small:       # lumahip_pool_create_small: a dozen chunks probed for milliseconds instead of all free memory for seconds
+            rc = self.L.lumahip_pool_create_small(ctx.h, n_float, n_y, n_uv, n_striped, C.byref(h))
+        else:
+            cfg = PoolConfig(chunk_bytes, n_float, n_y, n_uv, n_striped, keep_free, max_chunks, iters)
+            rc = self.L.lumahip_pool_create(ctx.h, C.byref(cfg), C.byref(h))
         if rc != OK:
             raise LumaHipError(rc, "lumahip_pool_create failed")
         self.h = h

@@ -51,10 +51,10 @@ class HbmChunkPool:
     first three region groups (channel-strided decode output), chosen by lumahip_pool_create through `ctx` (needs a quantizer
     set; probing overwrites the chunks).  Lists of uint8 tensors: .float, .y, .uv, .striped[g]; fastest first."""
 
-    def __init__(self, ctx, dev, n_float, n_y, n_uv, n_striped=0, keep_free=6 << 30, iters=2):
+    def __init__(self, ctx, dev, n_float, n_y, n_uv, n_striped=0, keep_free=6 << 30, iters=2, small=False):
         from . import capi
         self.dev = dev
-        self.pool = capi.Pool(ctx, n_float, n_y, n_uv, n_striped, CHUNK_BYTES, keep_free, 0, iters)
+        self.pool = capi.Pool(ctx, n_float, n_y, n_uv, n_striped, CHUNK_BYTES, keep_free, 0, iters, small=small)
         self.stats = self.pool.stats()
         self._ptr = {}
 

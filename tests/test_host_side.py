@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(L):
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(capi.SYMBOLS) == declared
-    assert lib.lumahip_abi_version() == 4
+    assert lib.lumahip_abi_version() == 5
 
 
 def test_host_lut_builder_matches_reference_tables(L, golden_dir):

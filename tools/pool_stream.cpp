@@ -1,7 +1,12 @@
 // tools/pool_stream.cpp -- a resident stream carved from the HBM chunk pool, from plain C++ over the C ABI (no Python, no
 // torch): what a long-running caller of lumahip_encode_frames_device does to get the rate bench.py reports as `value`.
 //
-//   pool_stream [batches frames_per_batch]      (default 12 x 20 frames of 3840x2160, PQ-11 Lu'v', profile 2)
+//   pool_stream [batches frames_per_batch [max_chunks]]      (default 12 x 20 frames of 3840x2160, PQ-11 Lu'v', profile 2)
+//
+// max_chunks > 0 = the SMALL pool: the pool may take at most that many 2 GiB chunks for its probes instead of
+// all free memory, keeps only what the `batches` need (2 batches: 2 float + 1 Y + 1 U/V chunk = 8 GB) and returns the rest; the
+// decode part is skipped.  Reported next to the two-lane rate: `pooled_frac_ordered` / `plain_frac_ordered`, the same launches
+// back to back on one stream (what roofline.frac of bench.py is).
 //
 // 1. one context, the quantizer of BASELINE configs[1];
 // 2. lumahip_pool_create: the free device memory in 2 GiB chunks, sorted into HBM region groups by traffic-only launches;
@@ -44,6 +49,7 @@ struct Stream {
 int main(int argc, char **argv)
 {
     const int nb = argc > 1 ? std::atoi(argv[1]) : 12, B = argc > 2 ? std::atoi(argv[2]) : 20;
+    const int max_chunks = argc > 3 ? std::atoi(argv[3]) : 0;
     const unsigned w = 3840, h = 2160;
     const size_t n1 = (size_t)w * h, n3 = 3 * n1;
     const int stride[3] = {(int)(((w + 31) & ~31u) * 2), (int)(((w + 31) & ~31u)), (int)(((w + 31) & ~31u))};   // vpx_img_alloc(I42016, w, h, 32)
@@ -65,13 +71,14 @@ int main(int argc, char **argv)
         return 1;
     }
     const int ypc = (int)(CH / ybytes), uvpc = (int)(CH / uvbytes);
-    const int nring = std::min(nb, 6);   // packed decoded frames: a ring of output batches (>> the 256 MB MALL)
+    const int nring = max_chunks > 0 ? 0 : std::min(nb, 6);   // packed decoded frames: a ring of output batches (>> the 256 MB MALL)
     lumahip_pool_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n_float = nb;
     cfg.n_y = (nb + ypc - 1) / ypc;
     cfg.n_uv = (nb + uvpc - 1) / uvpc;
     cfg.n_striped = (nring + 2) / 3;     // per region group: what the ROTATING allocations below draw from
+    cfg.max_chunks = max_chunks;
     lumahip_pool *pool = nullptr;
     const double tp0 = now();
     OK(lumahip_pool_create(ctx, &cfg, &pool));
@@ -135,7 +142,33 @@ int main(int argc, char **argv)
     }
     std::sort(tp.begin(), tp.end());
     std::sort(tq.begin(), tq.end());
+    // the same launches back to back on ONE stream (no unordered section), 8 rounds of the batches per timing
+    auto ordered = [&](Stream &s, double &sec) -> int {
+        const int R = 8;
+        const double t0 = now();
+        for (int r = 0; r < R; r++)
+            for (int b = 0; b < nb; b++) {
+                unsigned char *pl[3] = {s.y[b], s.u[b], s.v[b]};
+                const int rc = lumahip_encode_frames_device(ctx, s.rgb[b], n3, B, w, h, 1.0f, 2, pl, stride, psz, nullptr);
+                if (rc)
+                    return rc;
+            }
+        const int rc = lumahip_sync(ctx);
+        sec = (now() - t0) / R;
+        return rc;
+    };
+    std::vector<double> op, oq;
+    for (int k = 0; k < 9; k++) {
+        double t = 0;
+        OK(ordered(placed, t));
+        op.push_back(t);
+        OK(ordered(plain, t));
+        oq.push_back(t);
+    }
+    std::sort(op.begin(), op.end());
+    std::sort(oq.begin(), oq.end());
     const double px = (double)nb * B * n1;
+    const double fop = px * 15.0 / op[op.size() / 2] / 8e12, foq = px * 15.0 / oq[oq.size() / 2] / 8e12;
     const double rp = px / tp[tp.size() / 2] / 1e6, rq = px / tq[tq.size() / 2] / 1e6;
 
     // same bytes either way: compare the Y and U planes of the first and the last batch on the host
@@ -152,6 +185,22 @@ int main(int argc, char **argv)
     // 5. decode, into PACKED LumaFrames (include/luma/luma_frame.h:84-87: what LumaDecoder::decode() returns): the output buffer of
     //    every batch of a ring is allocated in stream order in the pool's ROTATING mode -- the caller does no group arithmetic --
     //    against the same ring in plain lumahip_malloc buffers; passes interleaved as above.  Same floats either way.
+    if (nring == 0) {   // the small pool: encode only
+        std::printf("{\"tool\": \"pool_stream\", \"small_pool_max_chunks\": %d, \"batches\": %d, \"frames_per_batch\": %d, "
+                    "\"pool_create_s\": %.2f, \"pooled_mpix_s\": %.0f, \"pooled_frac_of_8TBs\": %.4f, \"pooled_frac_ordered\": %.4f, "
+                    "\"plain_mpix_s\": %.0f, \"plain_frac_of_8TBs\": %.4f, \"plain_frac_ordered\": %.4f, \"planes_identical\": %s, \"pool\": %s}\n",
+                    max_chunks, nb, B, pool_s, rp, rp * 15e6 / 8e12, fop, rq, rq * 15e6 / 8e12, foq, same ? "true" : "false",
+                    lumahip_pool_stats_json(pool));
+        for (int b = 0; b < nb; b++) {
+            (void)lumahip_free(ctx, plain.rgb[b]);
+            (void)lumahip_free(ctx, plain.y[b]);
+            (void)lumahip_free(ctx, plain.u[b]);
+            (void)lumahip_free(ctx, plain.v[b]);
+        }
+        lumahip_pool_destroy(pool);
+        lumahip_destroy(ctx);
+        return same ? 0 : 2;
+    }
     std::vector<float *> rot(nring), pln(nring);
     for (int k = 0; k < nring; k++) {
         void *p = nullptr;
@@ -200,11 +249,11 @@ int main(int argc, char **argv)
         o += std::snprintf(gbuf + o, sizeof gbuf - (size_t)o, "%s%d", k ? ", " : "", groups[k]);
     std::printf("{\"tool\": \"pool_stream\", \"batches\": %d, \"frames_per_batch\": %d, \"passes\": %zu, "
                 "\"pool_create_s\": %.2f, \"pooled_mpix_s\": %.0f, \"pooled_frac_of_8TBs\": %.4f, "
-                "\"plain_mpix_s\": %.0f, \"plain_frac_of_8TBs\": %.4f, \"planes_identical\": %s, "
+                "\"plain_mpix_s\": %.0f, \"plain_frac_of_8TBs\": %.4f, \"pooled_frac_ordered\": %.4f, \"plain_frac_ordered\": %.4f, \"planes_identical\": %s, "
                 "\"decode_packed_rotating_mpix_s\": %.0f, \"decode_packed_rotating_frac_of_8TBs\": %.4f, "
                 "\"decode_packed_plain_mpix_s\": %.0f, \"decode_packed_plain_frac_of_8TBs\": %.4f, \"decode_ring_groups\": [%s], "
                 "\"decoded_identical\": %s, \"pool\": %s}\n",
-                nb, B, tp.size(), pool_s, rp, rp * 15e6 / 8e12, rq, rq * 15e6 / 8e12, same ? "true" : "false",
+                nb, B, tp.size(), pool_s, rp, rp * 15e6 / 8e12, rq, rq * 15e6 / 8e12, fop, foq, same ? "true" : "false",
                 drr, drr * 15e6 / 8e12, drq, drq * 15e6 / 8e12, gbuf, dsame ? "true" : "false", lumahip_pool_stats_json(pool));
     same = same && dsame;
     for (int k = 0; k < nring; k++)
