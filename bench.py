@@ -311,10 +311,10 @@ def run_default(L, args, config, rank, n_gpus, local_rank, use_dist, dev, sha):
         "decode_mpix_s": r["decode_mpix_s"], "decode_output_layout": r["decode_output_layout"],
         "roundtrip_mpix_s": r["roundtrip_mpix_s"],
         "decode_packed_layout": r.get("decode_packed_layout"),
-        # the reference's own decode layout (LumaDecoder::decode() returns a packed LumaFrame) at its best placement: the frames of
-        # a batch rotating over three chunks of three region groups (lumahip_decode_frames_device_rotating), two launches in flight
-        "decode_packed_mpix_s": ((r.get("decode_packed_layout") or {}).get("frame_rotating") or {}).get("value"),
-        "decode_packed_frac": ((r.get("decode_packed_layout") or {}).get("frame_rotating") or {}).get("frac_ordered"),
+        # the reference's own decode layout (LumaDecoder::decode() returns a packed LumaFrame) in buffers the LIBRARY allocates
+        # (lumahip_decoded_ring_*: the frames of a batch rotating over three region groups), two launches in flight / ordered
+        "decode_packed_mpix_s": ((r.get("decode_packed_layout") or {}).get("library_ring") or {}).get("value"),
+        "decode_packed_frac": ((r.get("decode_packed_layout") or {}).get("library_ring") or {}).get("frac_ordered"),
         "placement": dict({"mode": args.placement, "resident_stream": r["resident_stream"]}, **(pool.stats if pool is not None else {})),
     }
     if rank == 0:

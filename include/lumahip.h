@@ -37,7 +37,7 @@ extern "C" {
 
 /* ABI history.  The BINARY interface has only ever grown: every symbol of an earlier version is still exported with the same
  * signature, so a program linked against version 2 runs against this library.
- *   5 (round 6): addition -- lumahip_pool_create_small.
+ *   5 (round 6): additions -- lumahip_pool_create_small, lumahip_decoded_ring_* / lumahip_decode_frames_device_ring.
  *   4 (round 5): additions -- lumahip_rb_table_info, lumahip_lin_index_host, LUMAHIP_POOL_ROTATING, the lumahip_tune keys
  *     "ycbcr_rb_tables" / "rb_near_y" / "rb_near_c" / "lin_index"; lumahip_quantizer_info may answer search mode 7.  Behaviour:
  *     the half-input table's kernel choice is now a function of the stream's data only (feedback read four eligible launches
@@ -435,6 +435,27 @@ const char *lumahip_pool_stats_json(const lumahip_pool *pool);
  * round shows no contrast), *fastest (nullable) the fastest pair time seen, *nprobes (nullable) how often probe was called. */
 int lumahip_pool_find_groups(int n, double (*probe)(int i, int r, void *user), void *user, int *group_of, int *ngroups,
                              double *fastest, int *nprobes);
+
+/* ---- decoded batches in buffers the LIBRARY places -------------------------------------------------------------------
+ * The reference's decoder owns the frame it returns (LumaDecoder::decode() -> &m_frame, include/luma/luma_decoder.h:143-161
+ * there).  The device-resident counterpart: a ring of `nbatches` batches of up to `nframes` PACKED LumaFrames (channel c of a
+ * frame at frame + c*w*h) that the library allocates -- and places: the frames of a batch rotate over three buffers in three
+ * HBM region groups (lumahip_decode_frames_device_rotating's layout; a small pool finds the groups in well under a second), so
+ * ONE decode launch writes all three groups: 0.74 of the roofline, against 0.69 for a batch in a single caller-owned buffer
+ * wherever that buffer is (lumahip_decode_frames_device).  Without region groups to be found the ring falls
+ * back to plain allocations of the same layout.  ctx needs a quantizer set (the pool probes through it).
+ *   lumahip_decoded_ring_frame(ring, b, f)  device pointer of frame f of batch b (a packed LumaFrame of 3*w*h floats);
+ *   lumahip_decode_frames_device_ring(...)  decodes nframes <= the ring's frames into batch slot b (asynchronous, lanes apply);
+ *   lumahip_decoded_ring_info               info = {placed in region groups, batches, frames per batch, groups found}. */
+typedef struct lumahip_decoded_ring lumahip_decoded_ring;
+int lumahip_decoded_ring_create(lumahip_ctx *ctx, unsigned nbatches, unsigned nframes, unsigned w, unsigned h,
+                                lumahip_decoded_ring **out);
+void lumahip_decoded_ring_destroy(lumahip_decoded_ring *ring);
+int lumahip_decoded_ring_info(const lumahip_decoded_ring *ring, int info[4], size_t *frame_stride);
+float *lumahip_decoded_ring_frame(const lumahip_decoded_ring *ring, unsigned batch, unsigned frame);
+int lumahip_decode_frames_device_ring(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                      const size_t plane_frame_stride[3], unsigned nframes, int profile, float sc,
+                                      lumahip_decoded_ring *ring, unsigned batch);
 
 /* ---- many GPUs in one process ------------------------------------------------------------------------------------------
  * Replaces the reference's frame loop `for (...) encoder.encode(&frame)` (lumaenc.cpp:205-243; lumadec.cpp:112-160 for

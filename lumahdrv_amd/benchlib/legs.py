@@ -122,8 +122,11 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
         # "frame_rotating": the FRAMES of a batch rotate over three chunks of three region groups (frame f in chunk f % 3; every
         # frame still a packed LumaFrame) and the launch interleaves its tiles over the frames, so ONE launch writes all three
         # groups (lumahip_decode_frames_device_rotating): what the ordered figure of the packed layout can be
-        for how in ("pool_placed", "pool_rotating", "frame_rotating", "plain"):
-            ring = rot = frot = None
+        # "library_ring": the caller lets the LIBRARY allocate (lumahip_decoded_ring_create: its own small pool, the frames of a batch
+        # rotating over three region groups) -- the default a device-resident caller of the decoder gets; "caller_buffer": one
+        # caller-owned plain allocation per ring of batches, what lumahip_decode_frames_device is handed otherwise
+        for how in ("pool_placed", "pool_rotating", "frame_rotating", "library_ring", "caller_buffer"):
+            ring = rot = frot = lring = None
             if how == "pool_placed":
                 ring = pool.take_float(min(PACKED_RING, len(pool.float)))
                 if len(ring) < 3:
@@ -138,10 +141,19 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                 if min(len(g) for g in pool.striped) < PACKED_RING // 3 or 3 * per * n3 * 4 > CHUNK_BYTES:
                     continue
                 frot = pool.take_striped(PACKED_RING // 3)          # [[group 0 chunks], [group 1 chunks], [group 2 chunks]]
-            plain = torch.empty(PACKED_RING * B * n3, dtype=torch.float32, device=dev) if how == "plain" else None
+            elif how == "library_ring":
+                from lumahdrv_amd import capi
+                try:
+                    lring = capi.DecodedRing(ctx, PACKED_RING, B, w, h)
+                except Exception:
+                    continue
+            plain = torch.empty(PACKED_RING * B * n3, dtype=torch.float32, device=dev) if how == "caller_buffer" else None
             nring = len(ring) if ring is not None else PACKED_RING
 
-            def dec_packed(i, ring=ring, plain=plain, nring=nring, frot=frot):
+            def dec_packed(i, ring=ring, plain=plain, nring=nring, frot=frot, lring=lring):
+                if lring is not None:
+                    lring.decode(ptrs(i % nbatch)[2], st, psz, B, profile, sc, i % nring)
+                    return
                 if frot is not None:
                     k = i % nring
                     bases = [frot[g][k // 3].data_ptr() + (k % 3) * (-(-B // 3)) * n3 * 4 for g in range(3)]
@@ -158,6 +170,9 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
             pk[how] = {"value": round(rate(tp["wall_median"]), 1), "value_ordered": round(rate(tpo["wall_median"]), 1),
                        "kernel_ms": round(tp["dev_ms_median"] / K, 4), "kernel_ms_ordered": round(tpo["dev_ms_median"] / K, 4),
                        "frac_ordered": fr(tpo["dev_ms_median"] / K), "frac_overlapped": fr(tp["dev_ms_median"] / K), "batches_in_ring": nring}
+            if lring is not None:
+                pk[how].update(placed_in_region_groups=lring.placed, groups_found=lring.groups)
+                lring.close()
             if frot is not None:
                 pool.give_back([], [], [], frot)
             elif rot is not None:

@@ -29,6 +29,7 @@ SYMBOLS = [
     "lumahip_decode_frames_device", "lumahip_decode_frames_device_rotating", "lumahip_decode_display_frames_device", "lumahip_transform_color_space_device", "lumahip_synth_frames_device",
     "lumahip_device", "lumahip_encode_frames_device_planar", "lumahip_decode_frames_device_planar", "lumahip_begin_unordered", "lumahip_end_unordered",
     "lumahip_probe_decode_traffic_device",
+    "lumahip_decoded_ring_create", "lumahip_decoded_ring_destroy", "lumahip_decoded_ring_info", "lumahip_decoded_ring_frame", "lumahip_decode_frames_device_ring",
     "lumahip_pool_create", "lumahip_pool_create_small", "lumahip_pool_destroy", "lumahip_pool_alloc", "lumahip_pool_release", "lumahip_pool_available", "lumahip_pool_group_of",
     "lumahip_pool_stats_json", "lumahip_pool_find_groups",
     "lumahip_multi_create", "lumahip_multi_destroy", "lumahip_multi_shards", "lumahip_multi_ctx", "lumahip_multi_last_error", "lumahip_multi_used_rccl", "lumahip_multi_set_transport", "lumahip_multi_transport_note",
@@ -170,6 +171,13 @@ def lib():
     L.lumahip_probe_decode_traffic_device.argtypes = [vp, pp3, ip3, sp3, u, u, u, pp3, sz, i, C.POINTER(f)]
     L.lumahip_pool_create.argtypes = [vp, C.POINTER(PoolConfig), C.POINTER(vp)]
     L.lumahip_pool_create_small.argtypes = [vp, i, i, i, i, C.POINTER(vp)]
+    L.lumahip_decoded_ring_create.argtypes = [vp, u, u, u, u, C.POINTER(vp)]
+    L.lumahip_decoded_ring_destroy.argtypes = [vp]
+    L.lumahip_decoded_ring_destroy.restype = None
+    L.lumahip_decoded_ring_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.lumahip_decoded_ring_frame.argtypes = [vp, u, u]
+    L.lumahip_decoded_ring_frame.restype = vp
+    L.lumahip_decode_frames_device_ring.argtypes = [vp, pp3, ip3, sp3, u, i, f, vp, u]
     L.lumahip_pool_destroy.argtypes = [vp]
     L.lumahip_pool_destroy.restype = None
     L.lumahip_pool_alloc.argtypes = [vp, i, i, C.POINTER(vp)]
@@ -665,6 +673,38 @@ class Context:
     def d2h(self, arr: np.ndarray, src_ptr):
         assert arr.flags.c_contiguous
         self._chk(self.L.lumahip_memcpy_d2h(self.h, arr.ctypes.data, src_ptr, arr.nbytes))
+
+
+class DecodedRing:
+    """lumahip_decoded_ring: `nbatches` batches of up to `nframes` packed LumaFrames in buffers the LIBRARY allocates and places
+    (the frames of a batch rotate over three buffers in three HBM region groups); include/lumahip.h"""
+
+    def __init__(self, ctx: Context, nbatches, nframes, w, h):
+        self.L, self.ctx = lib(), ctx
+        h_ = C.c_void_p()
+        rc = self.L.lumahip_decoded_ring_create(ctx.h, nbatches, nframes, w, h, C.byref(h_))
+        if rc != OK:
+            raise LumaHipError(rc, "lumahip_decoded_ring_create failed")
+        self.h = h_
+        a, fs = (C.c_int * 4)(), C.c_size_t(0)
+        self.L.lumahip_decoded_ring_info(self.h, a, C.byref(fs))
+        self.placed, self.nbatches, self.nframes, self.groups, self.frame_stride = bool(a[0]), a[1], a[2], a[3], fs.value
+
+    def frame_ptr(self, batch, frame) -> int:
+        p = self.L.lumahip_decoded_ring_frame(self.h, batch, frame)
+        if not p:
+            raise LumaHipError(ERR_ARG, "no frame %d of batch %d in this ring" % (frame, batch))
+        return p
+
+    def decode(self, plane_ptrs, strides, plane_frame_strides, nframes, profile, sc, batch):
+        """lumahip_decode_frames_device_ring: nframes frames into batch slot `batch` (asynchronous)"""
+        self.ctx._chk(self.L.lumahip_decode_frames_device_ring(self.ctx.h, _arr3(C.c_void_p, plane_ptrs), _arr3(C.c_int, strides),
+                                                               _arr3(C.c_size_t, plane_frame_strides), nframes, profile, sc, self.h, batch))
+
+    def close(self):
+        if self.h:
+            self.L.lumahip_decoded_ring_destroy(self.h)
+            self.h = None
 
 
 class Pool:

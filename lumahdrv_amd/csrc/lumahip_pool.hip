@@ -137,6 +137,7 @@ struct lumahip_pool {
     std::string json;
     unsigned rot_next = 0;      // LUMAHIP_POOL_ROTATING: the group the next chunk should come from
     bool grouped = false;       // region groups were found and the chunks chosen by them
+    int ngroups = 0;            // how many
 };
 
 extern "C" void lumahip_pool_destroy(lumahip_pool *pool)
@@ -366,6 +367,9 @@ extern "C" int lumahip_pool_create(lumahip_ctx *ctx, const lumahip_pool_config *
         pool->chunks = kept;
     }
     pool->grouped = grouped;
+    for (const Chunk &c : pool->chunks)
+        if (grouped && c.group + 1 > pool->ngroups)
+            pool->ngroups = c.group + 1;
     snprintf(buf, sizeof buf, ", \"probes\": %d}", nprobe);
     js += buf;
     pool->json = js;
@@ -377,12 +381,14 @@ extern "C" int lumahip_pool_create(lumahip_ctx *ctx, const lumahip_pool_config *
 // chunks taken side by side already fall into two of them, and a read stream in one with its write streams in the other is what
 // the placed rate needs (0.734 - 0.737 of the roofline ordered for a 40-frame 4K stream in 2 + 1 + 1 chunks, against 0.67 - 0.68
 // in plain allocations, same process; 30 ms and 27 probes instead of 5.7 s and 427).  At six chunks the first round sometimes
-// sees one group only, hence the floor of eight and one retry with twice as many.
+// sees one group only, hence the floor of eight and one retry with twice as many.  STRIPED chunks (n_striped > 0: decoded output
+// spread over THREE groups) need the third group, which side-by-side allocations reach only after a few dozen chunks: 48 then.
 extern "C" int lumahip_pool_create_small(lumahip_ctx *ctx, int n_float, int n_y, int n_uv, int n_striped, lumahip_pool **out)
 {
     if (!ctx || !out || n_float < 0 || n_y < 0 || n_uv < 0 || n_striped < 0)
         return LUMAHIP_ERR_ARG;
     const int need = n_float + n_y + n_uv + 3 * n_striped;
+    const int first = n_striped > 0 ? std::max(48, need + 8) : std::max(8, need + 4);
     int rc = LUMAHIP_OK;
     for (int attempt = 0; attempt < 2; attempt++) {
         lumahip_pool_config cfg;
@@ -391,14 +397,133 @@ extern "C" int lumahip_pool_create_small(lumahip_ctx *ctx, int n_float, int n_y,
         cfg.n_y = n_y;
         cfg.n_uv = n_uv;
         cfg.n_striped = n_striped;
-        cfg.max_chunks = std::max(8, need + 4) << attempt;
+        cfg.max_chunks = first << attempt;
         rc = lumahip_pool_create(ctx, &cfg, out);
-        if (rc != LUMAHIP_OK || (*out)->grouped || attempt == 1)
+        if (rc != LUMAHIP_OK || attempt == 1 || ((*out)->grouped && (n_striped == 0 || (*out)->ngroups >= 3)))
             break;
         lumahip_pool_destroy(*out);
         *out = nullptr;
     }
     return rc;
+}
+
+// ---- decoded batches in buffers the LIBRARY places (include/lumahip.h "lumahip_decoded_ring") --------------------------------
+// One decode launch writes 12 of its 15 bytes per pixel.  A batch of packed LumaFrames in ONE caller-owned buffer puts all of
+// that into one region group (0.69 of the roofline, whatever the buffer); the frames of a batch rotating over three buffers of
+// three groups reach 0.74 (lumahip_decode_frames_device_rotating).  A caller that lets the library allocate gets exactly that:
+// the ring takes three-chunk sets from a small pool (one chunk per group), carves every batch's three thirds out of them and
+// hands out frame pointers; every frame is a packed LumaFrame.  No pool (tiny GPU share, no contrast): three plain allocations
+// per batch, same layout, same results.
+struct lumahip_decoded_ring {
+    lumahip_ctx *ctx = nullptr;
+    lumahip_pool *pool = nullptr;
+    unsigned nbatches = 0, nframes = 0, w = 0, h = 0;
+    size_t frame_stride = 0;                  // floats
+    std::vector<float *> base[3];             // per batch
+    std::vector<void *> plain;                // plain allocations (fallback), freed on destroy
+    bool placed = false;
+};
+
+extern "C" void lumahip_decoded_ring_destroy(lumahip_decoded_ring *r)
+{
+    if (!r)
+        return;
+    for (void *p : r->plain)
+        (void)lumahip_free(r->ctx, p);
+    lumahip_pool_destroy(r->pool);
+    delete r;
+}
+
+extern "C" int lumahip_decoded_ring_create(lumahip_ctx *ctx, unsigned nbatches, unsigned nframes, unsigned w, unsigned h,
+                                           lumahip_decoded_ring **out)
+{
+    if (!ctx || !out || nbatches == 0 || nframes == 0 || w == 0 || h == 0 || (w & 1) || (h & 1))
+        return LUMAHIP_ERR_ARG;
+    *out = nullptr;
+    lumahip_decoded_ring *r = new lumahip_decoded_ring();
+    r->ctx = ctx;
+    r->nbatches = nbatches;
+    r->nframes = nframes;
+    r->w = w;
+    r->h = h;
+    r->frame_stride = (size_t)3 * w * h;       // w, h even: a multiple of 4 floats, frames stay 16-byte aligned
+    const size_t CB = (size_t)2 << 30;
+    const size_t third = (((size_t)(nframes + 2) / 3) * r->frame_stride * sizeof(float) + ((size_t)1 << 20) - 1) >> 20 << 20;
+    for (int k = 0; k < 3; k++)
+        r->base[k].assign(nbatches, nullptr);
+    if (third <= CB) {
+        const unsigned per_chunk = (unsigned)(CB / third);
+        const int sets = (int)((nbatches + per_chunk - 1) / per_chunk);
+        lumahip_pool *pool = nullptr;
+        if (lumahip_pool_create_small(ctx, 0, 0, 0, sets, &pool) == LUMAHIP_OK && pool && pool->grouped && pool->ngroups >= 3 &&
+            lumahip_pool_available(pool, LUMAHIP_POOL_STRIPED, 0) >= sets && lumahip_pool_available(pool, LUMAHIP_POOL_STRIPED, 1) >= sets &&
+            lumahip_pool_available(pool, LUMAHIP_POOL_STRIPED, 2) >= sets) {
+            std::vector<unsigned char *> chunk[3];
+            bool ok = true;
+            for (int g = 0; g < 3 && ok; g++)
+                for (int s = 0; s < sets && ok; s++) {
+                    void *p = nullptr;
+                    ok = lumahip_pool_alloc(pool, LUMAHIP_POOL_STRIPED, g, &p) == LUMAHIP_OK;
+                    chunk[g].push_back((unsigned char *)p);
+                }
+            if (ok) {
+                // batch b: its three thirds in the three groups, the group of buffer 0 walking with b so that consecutive
+                // batches in flight start in different groups
+                for (unsigned b = 0; b < nbatches; b++)
+                    for (int k = 0; k < 3; k++)
+                        r->base[k][b] = (float *)(chunk[(k + b) % 3][b / per_chunk] + (size_t)(b % per_chunk) * third);
+                r->pool = pool;
+                r->placed = true;
+            }
+        }
+        if (!r->placed)
+            lumahip_pool_destroy(pool);
+    }
+    if (!r->placed) {
+        for (unsigned b = 0; b < nbatches; b++)
+            for (int k = 0; k < 3; k++) {
+                void *p = nullptr;
+                if (lumahip_malloc(ctx, &p, third) != LUMAHIP_OK) {
+                    lumahip_decoded_ring_destroy(r);
+                    return LUMAHIP_ERR_HIP;
+                }
+                r->plain.push_back(p);
+                r->base[k][b] = (float *)p;
+            }
+    }
+    *out = r;
+    return LUMAHIP_OK;
+}
+
+extern "C" int lumahip_decoded_ring_info(const lumahip_decoded_ring *r, int info[4], size_t *frame_stride)
+{
+    if (!r || !info)
+        return LUMAHIP_ERR_ARG;
+    info[0] = r->placed ? 1 : 0;
+    info[1] = (int)r->nbatches;
+    info[2] = (int)r->nframes;
+    info[3] = r->pool ? r->pool->ngroups : 0;
+    if (frame_stride)
+        *frame_stride = r->frame_stride;
+    return LUMAHIP_OK;
+}
+
+extern "C" float *lumahip_decoded_ring_frame(const lumahip_decoded_ring *r, unsigned batch, unsigned frame)
+{
+    if (!r || batch >= r->nbatches || frame >= r->nframes)
+        return nullptr;
+    return r->base[frame % 3][batch] + (size_t)(frame / 3) * r->frame_stride;
+}
+
+extern "C" int lumahip_decode_frames_device_ring(lumahip_ctx *ctx, const unsigned char *const planes_dev[3], const int stride[3],
+                                                 const size_t plane_frame_stride[3], unsigned nframes, int profile, float sc,
+                                                 lumahip_decoded_ring *r, unsigned batch)
+{
+    if (!ctx || !r || batch >= r->nbatches || nframes == 0 || nframes > r->nframes)
+        return LUMAHIP_ERR_ARG;
+    float *const bases[3] = {r->base[0][batch], r->base[1][batch], r->base[2][batch]};
+    return lumahip_decode_frames_device_rotating(ctx, planes_dev, stride, plane_frame_stride, nframes, r->w, r->h, profile, sc, bases,
+                                                 r->frame_stride);
 }
 
 extern "C" int lumahip_pool_alloc(lumahip_pool *pool, int kind, int group, void **chunk)

@@ -109,8 +109,9 @@ def test_bench_contract_single_gpu():
         # the reference's decoder returns the packed LumaFrame: that layout's decode rate, pool-placed and plainly allocated
         pk = r["decode_packed_layout"]
         # (a box with little free HBM gives the pool too few chunks for some of these legs: they are then absent, never wrong)
-        assert "plain" in pk
-        for how in ("pool_placed", "pool_rotating", "frame_rotating", "plain"):
+        assert "caller_buffer" in pk and "library_ring" in pk      # one caller-owned buffer / buffers the library allocates and places
+        assert r["decode_packed_mpix_s"] == pk["library_ring"]["value"] and r["decode_packed_frac"] == pk["library_ring"]["frac_ordered"]
+        for how in ("pool_placed", "pool_rotating", "frame_rotating", "library_ring", "caller_buffer"):
             if how in pk:
                 assert pk[how]["value"] > 0 and 0 < pk[how]["frac_ordered"] < 1 and pk[how]["kernel_ms_ordered"] > 0, pk
     assert "facade_hostfed" not in r                      # (--no-facade-hostfed: that leg has its own test below)

@@ -3,6 +3,8 @@ encoded into chunk-placed buffers give the bytes they give in plainly allocated 
 import numpy as np
 import pytest
 
+from lumahdrv_amd.placement import as_tensor as placement_tensor
+
 pytestmark = pytest.mark.gpu
 
 
@@ -195,5 +197,63 @@ def test_packed_frames_rotating_over_three_buffers_equal_the_packed_batch(oracle
                 ctx.decode_frames_device_rotating(pl, st, psz, B, w, h, profile, sc, bad, n3)
         torch.cuda.synchronize()
         assert bool(torch.isnan(big).all())
+        ctx.set_stream(None)
+        ctx.close()
+
+
+def test_library_allocated_decoded_ring_holds_the_packed_batch(oracle_mod):
+    """lumahip_decoded_ring_*: the caller lets the library allocate the decoded frames.  Every frame pointer it hands out holds, after
+    lumahip_decode_frames_device_ring, the packed LumaFrame lumahip_decode_frames_device writes for that frame -- Lu'v' and YCbCr,
+    full and short batches, every slot of the ring -- and frame 0 the oracle's; frames of a batch do not overlap; bad arguments
+    are refused.  Where the ring lives (region groups found or plain allocations) never changes a float."""
+    import torch
+    import lumahdrv_amd as L
+    from lumahdrv_amd import capi
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    for cfg, sc in (((L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005), 1.0), ((L.PTF_PQ, 10, L.CS_YCBCR, 10, 1000.0, 0.01), 20.0)):
+        ctx = L.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+        orc = o.Oracle(*cfg)
+        for (w, h), profile, B, slots in (((640, 96), 2, 7, 3), ((258, 34), 2, 4, 2), ((64, 32), 3, 1, 1)):
+            n3 = 3 * w * h
+            _, hs, st, _ = L.plane_geometry(w, h, profile)
+            psz = [hs[p] * st[p] for p in range(3)]
+            src = torch.empty(B * n3, dtype=torch.float32, device=dev)
+            planes = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+            ctx.synth_frames_device(src.data_ptr(), n3, B, w, h, 13, 0)
+            pl = [p.data_ptr() for p in planes]
+            ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, sc, profile, pl, st, psz)
+            ref = torch.empty(B * n3, dtype=torch.float32, device=dev)
+            ctx.decode_frames_device(pl, st, psz, B, w, h, profile, sc, ref.data_ptr(), n3)
+            ring = capi.DecodedRing(ctx, slots, B, w, h)
+            assert ring.nbatches == slots and ring.nframes == B and ring.frame_stride == n3
+            for slot in range(slots):
+                nf = B if slot % 2 == 0 else max(1, B - 2)            # a short batch into a full slot
+                ring.decode(pl, st, psz, nf, profile, sc, slot)
+                torch.cuda.synchronize()
+                spans = []
+                for f in range(nf):
+                    p = ring.frame_ptr(slot, f)
+                    assert p % 16 == 0
+                    got = placement_tensor(p, n3 * 4, dev).view(torch.int32)
+                    assert torch.equal(got, ref[f * n3:(f + 1) * n3].view(torch.int32)), (cfg[2], (w, h), profile, slot, f)
+                    spans.append((p, p + n3 * 4))
+                spans.sort()
+                assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+            pf = [planes[p][:psz[p]].cpu().numpy().reshape(hs[p], st[p]) for p in range(3)]
+            exp = orc.decode(pf, st, w, h, sc, profile)
+            got0 = placement_tensor(ring.frame_ptr(0, 0), n3 * 4, dev).view(torch.float32).cpu().numpy()
+            assert np.array_equal(got0.view(np.uint32), exp.reshape(-1).view(np.uint32))
+            with pytest.raises(L.LumaHipError):
+                ring.frame_ptr(slots, 0)
+            with pytest.raises(L.LumaHipError):
+                ring.frame_ptr(0, B)
+            with pytest.raises(L.LumaHipError):
+                ring.decode(pl, st, psz, B + 1, profile, sc, 0)       # more frames than a slot holds
+            with pytest.raises(L.LumaHipError):
+                ring.decode(pl, st, psz, B, profile, sc, slots)
+            ring.close()
         ctx.set_stream(None)
         ctx.close()
