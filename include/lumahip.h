@@ -558,8 +558,9 @@ int lumahip_time_launches(lumahip_ctx *ctx, int dir, int iters, const float *rgb
 int lumahip_quantize_probe_device(lumahip_ctx *ctx, uint16_t *out_dev, uint32_t first_bits, size_t n, int nonneg);
 
 /* Test probe: out[i] = the device powf (pow_glibc.hpp) of the float whose bit pattern is first_bits + i, raised to
- * y; regular != 0 selects the branch-free form + fallback that the YCbCr kernels use.  Lets the tests compare the
- * device function with the host libm exhaustively. */
+ * y; regular = 1 selects the branch-free form + fallback that the YCbCr kernels use; regular = 2 the folded form of the two
+ * narrow-range powers (y = 1/78.8438f: arguments in [2^-21, 1] only; y = 78.8438f: arguments in [0.7, 1.4) only).  Lets the
+ * tests compare the device function with the host libm exhaustively. */
 int lumahip_powf_probe_device(lumahip_ctx *ctx, float *out_dev, uint32_t first_bits, size_t n, float y, int regular);
 
 /* Test probe (YCbCr quantizers): out[i] = the luminance code of a pixel whose t = 219 y + 16 (y = its luma,

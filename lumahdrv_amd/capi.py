@@ -638,8 +638,8 @@ class Context:
                                                              _arr3(C.c_size_t, plane_frame_strides), iters, C.byref(ms)))
         return float(ms.value)
 
-    def powf_probe_device(self, out_ptr, first_bits, n, y, regular=True):
-        self._chk(self.L.lumahip_powf_probe_device(self.h, out_ptr, first_bits, n, y, int(bool(regular))))
+    def powf_probe_device(self, out_ptr, first_bits, n, y, regular=1):
+        self._chk(self.L.lumahip_powf_probe_device(self.h, out_ptr, first_bits, n, y, int(regular)))
 
     def quantize_probe_device(self, out_ptr, first_bits, n, nonneg=False):
         """uint16 codes of the n consecutive fp32 bit patterns from first_bits, through quantize_lut<mode, 4, nonneg>"""

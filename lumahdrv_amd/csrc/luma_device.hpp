@@ -221,28 +221,38 @@ LH_DEV float pq_encode_r(float val, const K &k, SlowAcc &acc)
         acc.umax = max(acc.umax, pw_range_key(*k.pw, __float_as_uint(x1)));
         Lp = powf_regular<false, false, false>(x1, n, *k.pw, acc.flag);
     }
-    return powf_regular<false, false, false>(div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp), m, *k.pw, acc.flag);
+    // ... and, being confined to [0.8359, 1.0088], it takes the folded 13-operation form where the kernel carries its table
+    // (pow_glibc.hpp powf_folded<1>: every float of [0.7, 1.4) returns what the complete chain returns)
+    const float x2 = div_nr(c1 + c2 * Lp, 1.0f + c3 * Lp);
+    if constexpr (std::is_same<typename std::remove_cv<typename std::remove_reference<decltype(*k.pw)>::type>::type, PowfTablesWide>::value)
+        return powf_folded<1>(x2, *k.pw);
+    else
+        return powf_regular<false, false, false>(x2, m, *k.pw, acc.flag);
 }
 
-// pq_decode_r<BOUNDED>: BOUNDED = the caller guarantees val in [0.0627, 1.79] (encode side: (219*y + 16)/255 with
-// y in [7e-7, 2]).  Then Vp = val^(1/m) lies in [0.9655, 1.0074], Vp - c1 in [0.129, 0.172] and c2 - c3*Vp in
-// [0.027, 0.81] are positive normal floats, their quotient in [0.16, 6.4], |log2|/n <= 16.8: no test anywhere.
-// Otherwise (decode side: val in [0, 1] after the reference's clamp, which also turns a NaN into 1): val is 0 (ZERO) or
-// a normal float -- it is a sum / difference of floats whose granularity is far above 2^-126 (ycbcr_inv), never a
-// denormal; Vp <= c1 gives a quotient of exactly 0 (ZERO) and Vp just above c1 one small enough for |log2|/n >= 126
-// (CHECK_E); the quotient itself is 0 or in [3e-9, 6.4], a normal float.
-// POSVAL (decode side, round 4): the caller has raised val to at least 2^-21 (see ycbcr_inv), so the first power needs no
-// zero select either; the quotient can still be exactly 0 (Vp <= c1) and tiny, hence ZERO and CHECK_E on the second.
-// ELIM: the bound on |log2| of the second power at which the unit goes to the complete functions: 126 where only powf's own
-// under / overflow handling must be avoided, 56 where the caller wants the result in [2^-56, 2^56] (ycbcr_inv_n<., ., 1>).
+// The second half of PQdec (BOUNDED / POSVAL / ELIM: see pq_decode_r below): from the first power's result Vp to L * t^(1/n), t = max(0, Vp - c1) / (c2 - c3 Vp).
+// (The folded form of this power over the 2 753 141 values t can take was measured slower and is not used: pow_glibc.hpp.)
+template <bool BOUNDED, bool POSVAL, int ELIM, typename K>
+LH_DEV float pq_decode_tail(float Vp, const K &k, SlowAcc &acc)
+{
+    const float n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
+    // std::max(0.0f, Vp - c1): with BOUNDED the difference is positive and the max is the identity
+    const float num = BOUNDED ? Vp - c1 : std_max(0.0f, Vp - c1);
+    const float t = div_nr(num, c2 - c3 * Vp);
+    return k.Lmax * powf_regular<!BOUNDED, false, BOUNDED ? 0 : ELIM>(t, 1.0f / n, *k.pw, acc.flag);
+}
+
 template <bool BOUNDED, bool POSVAL = false, int ELIM = 1, typename K>
 LH_DEV float pq_decode_r(float val, const K &k, SlowAcc &acc)
 {
-    const float m = 78.8438f, n = 0.1593f, c1 = 0.8359f, c2 = 18.8516f, c3 = 18.6875f;
-    const float Vp = powf_regular<!BOUNDED && !POSVAL, false, false>(val, 1.0f / m, *k.pw, acc.flag);
-    // std::max(0.0f, Vp - c1): with BOUNDED the difference is positive and the max is the identity
-    const float num = BOUNDED ? Vp - c1 : std_max(0.0f, Vp - c1);
-    return k.Lmax * powf_regular<!BOUNDED, false, BOUNDED ? 0 : ELIM>(div_nr(num, c2 - c3 * Vp), 1.0f / n, *k.pw, acc.flag);
+    const float m = 78.8438f;
+    // POSVAL: val in [2^-21, 1] -- the folded form's range (pow_glibc.hpp powf_folded<0>, checked for every float of [2^-32, 1])
+    float Vp;
+    if constexpr (POSVAL && std::is_same<typename std::remove_cv<typename std::remove_reference<decltype(*k.pw)>::type>::type, PowfTablesWide>::value)
+        Vp = powf_folded<0>(val, *k.pw);
+    else
+        Vp = powf_regular<!BOUNDED && !POSVAL, false, false>(val, 1.0f / m, *k.pw, acc.flag);
+    return pq_decode_tail<BOUNDED, POSVAL, ELIM>(Vp, k, acc);
 }
 
 template <int CS>

@@ -124,6 +124,10 @@ LH_DEV void stage_powf_tables(PowfTablesWide *t)
     stage_powf_tables(static_cast<PowfTables *>(t));
     for (int e = threadIdx.x; e < 2048; e += blockDim.x)
         pw_wide_entry(e, lt, t->wide[e][0], t->wide[e][1]);
+    for (int e = threadIdx.x; e < FOLD_A_LEN; e += blockDim.x)
+        pw_fold_entry<0>(e, lt, t->foldA[e][0], t->foldA[e][1]);
+    if (threadIdx.x < 16)
+        pw_fold_entry<1>(threadIdx.x, lt, t->foldC[threadIdx.x][0], t->foldC[threadIdx.x][1]);
 }
 
 LH_DEV int lds_lut_bytes(const QuantDev &q) { return ((q.lut_len + q.pad) * 4 + 15) & ~15; }

@@ -256,7 +256,7 @@ int decode_impl(lumahip_ctx *c, const unsigned char *const planes[3], const int 
     size_t lds = lds_bytes(c, false, cs_eff);
     if (cs_eff == CS_YCBCR && c->q.ytab && !yt)
         lds -= ((size_t)(c->q.lut_len + c->q.pad) * 4 + 15) & ~(size_t)15;   // (display variant: no y table)
-    const int threads = block_threads_for(c, lds);
+    const int threads = block_threads_for(c, lds, false, cs_eff == CS_YCBCR);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     for (int k = 0; k < 3; k++)

@@ -166,7 +166,7 @@ int encode_frames_device_impl(lumahip_ctx *c, const float *const rgb[3], size_t 
     }
     const size_t lds = lds_bytes(c, true, cs_eff, ycode, half != nullptr);
     const bool long_launch = (unsigned long long)w * h * nframes >= 60000000ull;   // >= 7 4K frames
-    const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR);
+    const int threads = block_threads_for(c, lds, long_launch && cs_eff != CS_YCBCR, cs_eff == CS_YCBCR && !half);
     if (!make_geom(a.g, w, h, vw, threads / 64, nframes))
         return fail(c, LUMAHIP_ERR_ARG, "batch too large: more than 2^31 tiles in one launch");
     for (int k = 0; k < 3; k++)

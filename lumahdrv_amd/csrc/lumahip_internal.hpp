@@ -269,7 +269,7 @@ struct DisplayParams {
 
 // ---- lumahip_launch.hip
 size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode = false, bool half = false);   // ycode: the composite-record encode kernels; half: + the half-input table
-int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false);
+int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves = false, bool valu_bound = false);
 int grid_for(const lumahip_ctx *c, int threads, int total_tiles, int dir, int few_writers = 0, int ycbcr = 0);   // few_writers: 0 no, 1 yes, 2 yes with the colour planes in separate buffers; ycbcr: 0 no, 1 yes, 2 the half-input encode kernels
 // ---- lumahip_core.hip
 int ensure_search_index(lumahip_ctx *c);   // every encode-side launch calls this first (lazy build / process-wide cache)

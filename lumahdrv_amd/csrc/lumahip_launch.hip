@@ -42,10 +42,15 @@ size_t lds_bytes(const lumahip_ctx *c, bool encode_side, int cs_eff, bool ycode,
 //   - `few_waves` (the encode kernels of the HBM-bound colour spaces on long launches, see grid_for): three 256-thread
 //     workgroups per CU are the fastest configuration measured, so the workgroup stays at 256 threads as long as three
 //     copies of the table fit the CU's LDS (LOG-12's 42 KiB of records: 3.9 % faster than four 512-thread workgroups).
-int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves)
+int block_threads_for(const lumahip_ctx *c, size_t lds, bool few_waves, bool valu_bound)
 {
     if (c->block_forced)
         return c->block_threads;
+    // The per-pixel YCbCr kernels hold ~128 VGPRs: four waves per SIMD, i.e. TWO 512-thread workgroups per CU, are resident
+    // whatever the LDS allows, so their workgroup stays at 512 threads as long as two copies of the tables fit (round 6: the
+    // folded-powf tables took the decode kernels from 49 to 55 KiB; 1024-thread workgroups would only coarsen the shares).
+    if (valu_bound && lds > 32 * 1024 && 2 * lds <= LUMAHIP_LDS_PER_WORKGROUP)
+        return 512;
     if (few_waves && c->block_threads == 256 && 3 * lds <= LUMAHIP_LDS_PER_WORKGROUP)
         return 256;
     if (lds > 53 * 1024)

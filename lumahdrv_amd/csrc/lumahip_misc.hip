@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void k_powf_probe(float *out, uint32_t first_b
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float x = __uint_as_float(first_bits + (uint32_t)i);
         float r;
-        if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
+        if (regular == 2) {   // the folded 13-operation form of the two narrow-range powers (pow_glibc.hpp powf_folded): y says which
+            r = y < 1.0f ? powf_folded<0>(x, s_pw) : powf_folded<1>(x, s_pw);
+        } else if (regular) {  // the branch-free form with its fallback, exactly as the YCbCr kernels use it
             bool slow = false;
             r = powf_regular<true, true, true>(x, y, s_pw, slow);
             if (slow)

@@ -69,10 +69,18 @@ static const PowfTables kPowfTablesHost = {LH_POWF_LOG2_TAB, LH_POWF_EXP2_TAB};
 // bits 19..29 of (ix - OFF) replaces the 16-entry read, the arithmetic shift, the int -> double conversion and the fp64
 // add `logc + (double)k` (10 issue cycles per powf on gfx950; the sum is the same single rounding, done when the table
 // is filled).  Arguments outside 2^-64 .. 2^64 take the complete function (pw_range_key).
+//
+// Round 6 adds the tables of the FOLDED form (powf_folded below) for the two powers whose arguments live in one narrow, fully
+// enumerable range -- PQdec's first power val^(1/m), val in [2^-21, 1], and PQenc's second power q^m, q in [0.7, 1.4):
+//   foldA[e] = {invc[i] * 2^21, (1/m) * (logc[i] + k)}   e = (k + 21) * 16 + i, k in [-21, 0]   (352 entries)
+//   foldC[i] = {invc[i],        m * logc[i]}              (k = 0 throughout)
+constexpr int FOLD_A_KMIN = -21, FOLD_A_LEN = (0 - FOLD_A_KMIN + 1) * 16;
 struct PowfTablesWide : PowfTables {
     double wide[2048][2];
+    double foldA[FOLD_A_LEN][2];
+    double foldC[16][2];
 };
-static_assert(sizeof(PowfTablesWide) == sizeof(PowfTables) + 32768, "layout");
+static_assert(sizeof(PowfTablesWide) == sizeof(PowfTables) + 32768 + FOLD_A_LEN * 16 + 256, "layout");
 
 // entry e of the wide table from the 16-entry table: e = (k & 127) * 16 + i
 LH_HD void pw_wide_entry(int e, const double (&lt)[16][2], double &invc, double &y0)
@@ -249,6 +257,44 @@ LH_HD uint32_t pw_range_limit(const PowfTablesWide &) { return 128u << 23; }
 LH_HD uint32_t pw_range_low(const PowfTables &) { return 0x00800000u; }
 LH_HD uint32_t pw_range_low(const PowfTablesWide &) { return 0x3f330000u - (64u << 23); }
 
+// exp2_inline's argument split: ylogx = k/32 + rr with rr in [-1/64, 1/64], s = 2^(k/32) from the 32-entry table
+template <typename Tab>
+LH_HD void pw_exp2_split(double ylogx, const Tab &T, double &rr, double &s)
+{
+    const double SHIFT = 0x1.8p+52 / 32;
+    double kd = ylogx + SHIFT;
+    const uint64_t ki = pw_asuint64(kd);
+    kd -= SHIFT;
+    rr = ylogx - kd;
+    // s = bits(tab[ki % 32] + (ki << 47)): the low 32 bits of ki << 47 are zero, so only the high word changes -- one
+    // 32-bit shift-add on the device (the compiler otherwise builds the 64-bit shift and add out of five instructions)
+    const uint64_t t0 = T.exp2_tab[ki % 32];
+#if defined(__HIP_DEVICE_COMPILE__)
+    s = __hiloint2double((int)((uint32_t)(t0 >> 32) + ((uint32_t)ki << 15)), (int)(uint32_t)t0);
+#else
+    s = pw_asdouble(t0 + (ki << (52 - 5)));
+#endif
+}
+
+// The polynomial of exp2_inline and the final scaling.  e_powf.c evaluates 1 + C2 r + r^2 (C1 + C0 r) as two independent halves
+// joined by a third fma (five operations with the scaling); this is Horner's form of the same polynomial (four).  The two differ
+// in the last bits of the DOUBLE now and then, never in the float it is rounded to: for each of the four PQ exponents, every
+// positive normal x with |y log2 x| < 126 -- 4 x 2^31 arguments less the out-of-range ones -- returns the same float either way
+// (tools/bench/powf_variants.cpp on the host, 32 s; tests/test_gpu_exhaustive.py sweeps the device function against the host
+// libm over the same arguments).  powf_glibc above keeps glibc's order and is what every exceptional pixel is redone with.
+template <bool ZERO>
+LH_HD float pw_exp2_tail(double rr, double s, bool zero)
+{
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double e = __builtin_fma(C0, rr, C1);
+    e = __builtin_fma(e, rr, C2);
+    e = __builtin_fma(e, rr, 1.0);
+    e = e * s;
+    if (ZERO)
+        return zero ? 0.0f : (float)e;
+    return (float)e;
+}
+
 // Straight-line form for the arguments the PQ transforms see almost always: x positive, normal and finite (or +0
 // when ZERO) with |y*log2(x)| < 126; y is one of the four positive PQ exponents.  For those arguments it performs
 // exactly the arithmetic of powf_glibc above (same operations, same order) without any of its branches; for
@@ -291,28 +337,84 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
         const double lim = CHECK_E == 1 ? 126.0 : (double)CHECK_E;
         slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(lim) >> 47)));
     }
-    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
-    const double SHIFT = 0x1.8p+52 / 32;
-    double kd = ylogx + SHIFT;
-    const uint64_t ki = pw_asuint64(kd);
-    kd -= SHIFT;
-    const double rr = ylogx - kd;
-    // s = bits(tab[ki % 32] + (ki << 47)): the low 32 bits of ki << 47 are zero, so only the high word changes -- one
-    // 32-bit shift-add on the device (the compiler otherwise builds the 64-bit shift and add out of five instructions)
-    const uint64_t t0 = T.exp2_tab[ki % 32];
+    double rr, s;
+    pw_exp2_split(ylogx, T, rr, s);
+    return pw_exp2_tail<ZERO>(rr, s, zero);
+}
+
+// ---- the folded form: 13 fp64 operations instead of 17 -----------------------------------------------------------------
+// Two of the four powers of a PQ pair take their argument from ONE narrow range (luma_device.hpp proves it at the call sites):
+//   WHICH = 0   PQdec's first power, val^(1/m): val in [2^-21, 1] after the reference's clamp (FOLD_A_KMIN);
+//   WHICH = 1   PQenc's second power, q^m: q = (c1 + c2 Lp) / (1 + c3 Lp) in [0.8359, 1.0088], inside [OFF, 2 OFF) =
+//               [0.69921875, 1.3984375) where k = 0.
+// Over such a range the function can be checked for EVERY argument, so any evaluation of glibc's polynomials that returns
+// glibc's float for all of them is as good as glibc's own order.  This one folds the exponent into the log2 polynomial (y A0 ..
+// y A4 as constants, y (logc + k) in the table: ylogx comes straight out of the last fma) and walks it in Horner's form: five
+// fma from r to ylogx instead of eight operations, plus the Horner exp2 tail.  Checked: val in [2^-32, 1] (268 435 457
+// arguments) and q in [OFF, 2 OFF) (8 388 608): no float differs from the exact chain's (tools/bench/powf_variants.cpp);
+// tests/test_gpu_exhaustive.py runs the same sweep through the device code.  (The other two powers -- t^(1/n) over 2.6e8
+// arguments, x^n over 2^31 -- do NOT survive the same treatment as functions of an arbitrary float: 6 to 10 floats differ;
+// profiles/r06_ycbcr_powf_ledger.txt.)
+// The SECOND power of PQdec, t^(1/n), has a small argument set too -- t = (Vp - c1) / (c2 - c3 Vp) is a function of the first
+// power's float result, 2 753 141 values -- and the folded form returns glibc's float for all of them but one
+// (t = 0x1.7bd282p-6, where glibc's double lands within a unit of a rounding boundary).  It was built, proven and MEASURED
+// SLOWER: 13 or 14 operations in Horner's order are one long dependency chain per power, and with the exception's bookkeeping and
+// a second set of folded coefficients the decode kernel ran 2.5 - 2.9 % slower than with powf_regular for that power
+// (profiles/r06_ycbcr_powf_ledger.txt).  Not kept.
+template <int WHICH>
+LH_HD double pw_fold_y()
+{
+    const float m = 78.8438f;
+    return WHICH == 0 ? (double)(1.0f / m) : (double)m;
+}
+// entry e of the folded tables from the 16-entry table
+template <int WHICH>
+LH_HD void pw_fold_entry(int e, const double (&lt)[16][2], double &invc, double &y0)
+{
+    const int i = e & 15, k = WHICH == 0 ? (e >> 4) + FOLD_A_KMIN : 0;
+    // WHICH 0: the argument's exponent field is raised by 21 before it is split (so that the table index starts at 0): z comes
+    // out scaled by 2^-21 and the reciprocal carries the 2^21 -- both exact, r = z invc - 1 is the same double
+    invc = WHICH == 0 ? lt[i][0] * 0x1p21 : lt[i][0];
+    y0 = pw_fold_y<WHICH>() * (lt[i][1] + (double)k);
+}
+
+template <int WHICH>
+LH_HD float powf_folded(float x, const PowfTablesWide &T)
+{
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    const double Y = pw_fold_y<WHICH>();
+    const uint32_t ix = pw_asuint(x);
+    double invc, y0, z;
+    if (WHICH == 0) {
+        const uint32_t tmp = ix - (0x3f330000u + ((uint32_t)FOLD_A_KMIN << 23));   // (FOLD_A_KMIN < 0: the offset shrinks)
+        const uint32_t top = tmp & 0xff800000u;
+        z = (double)pw_asfloat(ix - top);                                           // z * 2^-21
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double s = __hiloint2double((int)((uint32_t)(t0 >> 32) + ((uint32_t)ki << 15)), (int)(uint32_t)t0);
+        uint32_t e;
+        asm("v_bfe_u32 %0, %1, 19, 9" : "=v"(e) : "v"(tmp));
 #else
-    const double s = pw_asdouble(t0 + (ki << (52 - 5)));
+        const uint32_t e = (tmp >> 19) & 511u;
 #endif
-    const double zz = __builtin_fma(C0, rr, C1);
-    const double rr2 = rr * rr;
-    double e = __builtin_fma(C2, rr, 1.0);
-    e = __builtin_fma(zz, rr2, e);
-    e = e * s;
-    if (ZERO)
-        return zero ? 0.0f : (float)e;
-    return (float)e;
+        invc = T.foldA[e][0];
+        y0 = T.foldA[e][1];
+    } else {
+        const uint32_t e = ((ix - 0x3f330000u) >> 19) & 15u;
+        z = (double)x;
+        invc = T.foldC[e][0];
+        y0 = T.foldC[e][1];
+    }
+    const double r = __builtin_fma(z, invc, -1.0);
+    // (Estrin's grouping of the same folded polynomial -- one operation more, a shorter chain -- measured 1 % slower; glibc's
+    //  grouping of the exp2 tail 2 % slower: profiles/r06_ycbcr_powf_ledger.txt)
+    double h = __builtin_fma(Y * A0, r, Y * A1);
+    h = __builtin_fma(h, r, Y * A2);
+    h = __builtin_fma(h, r, Y * A3);
+    h = __builtin_fma(h, r, Y * A4);
+    const double ylogx = __builtin_fma(h, r, y0);
+    double rr, s;
+    pw_exp2_split(ylogx, T, rr, s);
+    return pw_exp2_tail<false>(rr, s, false);
 }
 
 }  // namespace lh

@@ -269,6 +269,38 @@ def test_device_powf_equals_host_libm_for_every_nonnegative_float(oracle_mod, re
     assert total_bad == 0
 
 
+def test_folded_powf_equals_host_libm_for_every_argument_of_its_range(oracle_mod):
+    """pow_glibc.hpp powf_folded (round 6: 13 fp64 operations instead of 17 for the two PQ powers whose arguments come from one
+    narrow range) on the GPU vs this host's libm powf, bit for bit, for EVERY float of those ranges and beyond them as far as the
+    tables reach (the binades split at OFF = 0.69921875): val^(1/m) for val in [2^-21, 1] (PQdec's first power after the reference's
+    clamp; every float of [OFF 2^-21, 2 OFF) is swept) and q^m for q in [OFF, 2 OFF) (PQenc's second power lives in [0.8359, 1.0088])."""
+    import torch
+    import lumahdrv_amd as L
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    m = np.float32(78.8438)
+
+    def bits(v):
+        return int(np.float32(v).view(np.uint32))
+    for y, lo, hi in ((float(np.float32(1.0) / m), bits(0.69921875 * 2.0 ** -21), bits(1.3984375) - 1), (float(m), bits(0.69921875), bits(1.3984375) - 1)):
+        n = 1 << 26
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        first, swept = lo, 0
+        while first <= hi:
+            cnt = min(n, hi - first + 1)
+            cnt4 = (cnt + 3) // 4 * 4                        # (the compare helper walks whole words; the last word's padding is not compared)
+            ctx.powf_probe_device(out.data_ptr(), first, cnt4, y, 2)
+            bad, fb = o.powf_compare(out[:cnt].cpu().numpy(), first, y)
+            assert bad == 0, ("y=%r first mismatch at bits 0x%08x" % (y, fb))
+            first += cnt
+            swept += cnt
+        assert swept == hi - lo + 1 and swept > (180_000_000 if y < 1 else 8_000_000)
+    ctx.set_stream(None)
+    ctx.close()
+
+
 def test_ycbcr_decode_every_code_triple_of_the_hdr10_recipe(oracle_mod):
     """(3): PQ 10-bit / YCbCr 10-bit chroma, max 1000 cd/m2, preScaling 20 (README.md:46-59 of the reference; BASELINE
     configs[2]).  Frame k holds Y code k everywhere, Cb = row index, Cr = column index; profile 3 (4:4:4) so that every

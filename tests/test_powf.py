@@ -16,4 +16,5 @@ def test_restated_powf_matches_host_libm(tmp_path):
     r = subprocess.run([exe, "509"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout.splitlines()[-1]
-    assert r.stdout.count("0 mismatches") == 5   # four exponents + the total
+    assert r.stdout.count("0 mismatches") == 7   # four exponents + the two ranges of the folded form (round 6) + the total
+    assert r.stdout.count("folded form") == 2

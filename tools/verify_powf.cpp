@@ -45,6 +45,10 @@ int main(int argc, char **argv)
         memcpy(wide.exp2_tab, et, sizeof et);
         for (int e = 0; e < 2048; e++)
             lh::pw_wide_entry(e, lt, wide.wide[e][0], wide.wide[e][1]);
+        for (int e = 0; e < lh::FOLD_A_LEN; e++)
+            lh::pw_fold_entry<0>(e, lt, wide.foldA[e][0], wide.foldA[e][1]);
+        for (int e = 0; e < 16; e++)
+            lh::pw_fold_entry<1>(e, lt, wide.foldC[e][0], wide.foldC[e][1]);
     }
     std::atomic<uint64_t> fast16{0}, fastw{0};
     for (int e = 0; e < 4; e++) {
@@ -90,6 +94,43 @@ int main(int argc, char **argv)
                (unsigned long long)bad.load());
         total_bad += bad;
         total += cnt;
+    }
+    // the folded form (round 6) over everything its tables reach -- the binades' split point is OFF = 0x3f330000 = 0.69921875:
+    // val^(1/m) for val in [OFF 2^-21, 2 OFF) -- the kernels hand it [2^-21, 1] -- and q^m for q in [OFF, 2 OFF) -- the kernels
+    // hand it [0.8359, 1.0088].  Every float unless stride > 7.
+    {
+        const uint64_t fs = stride > 7 ? 7 : stride;
+        const struct {
+            int which;
+            float y, lo, hi;
+        } dom[2] = {{0, ys[2], 0.69921875f * 0x1p-21f, 1.3984375f}, {1, ys[1], 0.69921875f, 1.3984375f}};
+        for (const auto &d : dom) {
+            const uint32_t b0 = lh::pw_asuint(d.lo), b1 = lh::pw_asuint(d.hi) - 1;
+            std::atomic<uint64_t> bad{0}, cnt{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    uint64_t b = 0, c = 0;
+                    for (uint64_t u = (uint64_t)b0 + t * fs; u <= b1; u += nt * fs) {
+                        const float x = lh::pw_asfloat((uint32_t)u);
+                        const float a = d.which == 0 ? lh::powf_folded<0>(x, wide) : lh::powf_folded<1>(x, wide);
+                        c++;
+                        if (!same(a, powf(x, d.y))) {
+                            if (b < 5)
+                                fprintf(stderr, "MISMATCH (folded %d) x=%a (0x%08x): %a libm %a\n", d.which, x, (unsigned)u, a, powf(x, d.y));
+                            b++;
+                        }
+                    }
+                    bad += b;
+                    cnt += c;
+                });
+            for (auto &x : th)
+                x.join();
+            printf("folded form, y=%-14a (%.9g), x in [%g, %g): %llu arguments, %llu mismatches\n", d.y, d.y, d.lo, d.hi,
+                   (unsigned long long)cnt.load(), (unsigned long long)bad.load());
+            total_bad += bad;
+            total += cnt;
+        }
     }
     printf("straight-line form applied to %llu (16-entry table) / %llu (wide table) of them\n",
            (unsigned long long)fast16.load(), (unsigned long long)fastw.load());
