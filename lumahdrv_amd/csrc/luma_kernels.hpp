@@ -207,7 +207,7 @@ LH_DEV void stage_tables(unsigned char *smem, const QuantDev &q, const float *ha
 
 // ---- sample stores / loads ------------------------------------------------------------------------
 // Every frame byte is touched exactly once, so all global accesses of the pixel stream are non-temporal
-// (`nt`): measured +4-5 % on the encode access pattern (tools/experiments/membench2.hip, profiles/r01_membench.txt).
+// (`nt`): measured +4-5 % on the encode access pattern (profiles/r01_membench.txt).
 typedef float lh_v4f __attribute__((ext_vector_type(4)));
 typedef float lh_v2f __attribute__((ext_vector_type(2)));
 typedef unsigned lh_v2u __attribute__((ext_vector_type(2)));
