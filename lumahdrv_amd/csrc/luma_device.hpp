@@ -195,12 +195,15 @@ LH_DEV float pq_decode(float val, const K &k)
 struct SlowAcc {
     uint32_t umax = 0;
     uint32_t umin = 0xffffffffu;  // running unsigned min of (bits(x) - 1) over arguments that must be +0 or >= pw_range_low
+    uint32_t emax = 0;            // running unsigned max of the high word of |y log2 t| over PQdec's second powers (pow_glibc.hpp EMAX)
     bool flag = false;
 };
-template <typename K>
+// ELIM: the bound pq_decode_r's callers put on |log2| of PQdec's second power (1 = powf's own 126); 0 = no such power in the unit
+template <int ELIM = 0, typename K>
 LH_DEV bool slow_any(const SlowAcc &a, const K &k)
 {
-    return a.flag || a.umax >= pw_range_limit(*k.pw) || a.umin < pw_range_low(*k.pw) - 1u;
+    return a.flag || a.umax >= pw_range_limit(*k.pw) || a.umin < pw_range_low(*k.pw) - 1u ||
+           (ELIM != 0 && a.emax >= pw_emax_limit(ELIM == 1 ? 126 : ELIM));
 }
 
 // pq_encode_r<ANYVAL>: with ANYVAL (decode side: val is a table value, possibly 0, tiny, negative or NaN) the first
@@ -239,7 +242,11 @@ LH_DEV float pq_decode_tail(float Vp, const K &k, SlowAcc &acc)
     // std::max(0.0f, Vp - c1): with BOUNDED the difference is positive and the max is the identity
     const float num = BOUNDED ? Vp - c1 : std_max(0.0f, Vp - c1);
     const float t = div_nr(num, c2 - c3 * Vp);
-    return k.Lmax * powf_regular<!BOUNDED, false, BOUNDED ? 0 : ELIM>(t, 1.0f / n, *k.pw, acc.flag);
+    if constexpr (!BOUNDED && std::is_same<typename std::remove_cv<typename std::remove_reference<decltype(*k.pw)>::type>::type, PowfTablesWide>::value)
+        // the bound on |log2| is tested once per unit on a running maximum (pow_glibc.hpp EMAX; slow_any<ELIM>)
+        return k.Lmax * powf_regular<true, false, 0>(t, 1.0f / n, *k.pw, acc.flag, &acc.emax);
+    else
+        return k.Lmax * powf_regular<!BOUNDED, false, BOUNDED ? 0 : ELIM>(t, 1.0f / n, *k.pw, acc.flag);
 }
 
 template <bool BOUNDED, bool POSVAL = false, int ELIM = 1, typename K>
@@ -503,11 +510,15 @@ LH_DEV void ycbcr_inv(float c0, float c1, float c2, const K &k, float &r, float 
         // c1^m = 0.8359^78.8438 = 7.3e-7 decodes to exactly 0: Vp = val^(1/m) <= c1, so std::max(0, Vp - c1) = 0, the quotient is 0
         // and L * 0^(1/n) = 0.  Clamping to [2^-21, 1] instead (2^-21 = 4.8e-7: Vp = 0.8314 < c1) therefore changes no result
         // and hands the first power a positive normal argument in every case: no zero select, no lower-bound test for green
-        // (a difference of differences with no short proof of one), same two instructions for the clamp.  (The compiler turns
-        // the compare + select pairs into v_min_f32 / v_max_f32: a NaN becomes 1, as in the reference's std::min / std::max.)
-        red = std_max(0x1p-21f, std_min(1.0f, red));
-        green = std_max(0x1p-21f, std_min(1.0f, green));
-        blue = std_max(0x1p-21f, std_min(1.0f, blue));
+        // (a difference of differences with no short proof of one).
+        // One v_med3_f32 per channel (round 6) instead of v_min + v_max (where a NaN became 1, as in the reference's std::min /
+        // std::max -- the complete functions below still do exactly that): the median of {v, 2^-21, 1} IS that clamp for every
+        // non-NaN v, and a NaN cannot reach this line unflagged -- y is a finite table value or the unit is flagged (c0), the
+        // chroma terms are finite for codes <= maxC and larger codes flag the unit (ycbcr_inv_n) -- so what the median makes of
+        // one is discarded with the rest of the straight-line results.
+        red = __builtin_amdgcn_fmed3f(red, 0x1p-21f, 1.0f);
+        green = __builtin_amdgcn_fmed3f(green, 0x1p-21f, 1.0f);
+        blue = __builtin_amdgcn_fmed3f(blue, 0x1p-21f, 1.0f);
         r = pq_decode_r<false, true, ELIM>(red, k, slow);
         g = pq_decode_r<false, true, ELIM>(green, k, slow);
         b = pq_decode_r<false, true, ELIM>(blue, k, slow);
@@ -586,7 +597,7 @@ LH_DEV void ycbcr_inv_n(const float (&c0)[N], const float (&c1)[N], const float 
             b[i] = div_nr_r(b[i], k.sc, k.rsc);
         }
     }
-    if (__builtin_expect(slow_any(slow, k), 0)) {
+    if (__builtin_expect(slow_any<ELIM>(slow, k), 0)) {
         for (int i = 0; i < N; i++) {  // not unrolled: cold code
             float d1 = c1[i], d2 = c2[i];
             if constexpr (CT) {
@@ -621,12 +632,12 @@ LH_DEV bool ycbcr_inv_green_n(const float (&c0)[N], const float (&c1)[N], const 
         const float y = c0[i];
         const float blue = y + c1[i], red = y + c2[i];
         float green = div_nr_r((y - 0.2627f * red) - 0.0593f * blue, 0.6780f, k.r0678);
-        green = std_max(0x1p-21f, std_min(1.0f, green));   // (see ycbcr_inv on the lower bound)
+        green = __builtin_amdgcn_fmed3f(green, 0x1p-21f, 1.0f);   // (see ycbcr_inv on the lower bound and on the median)
         g[i] = pq_decode_r<false, true, ELIM>(green, k, slow);
         if constexpr (SCDIV == 1)
             g[i] = div_nr_r(g[i], k.sc, k.rsc);
     }
-    const bool redo = slow_any(slow, k);
+    const bool redo = slow_any<ELIM>(slow, k);
     if (__builtin_expect(redo, 0)) {
         for (int i = 0; i < N; i++) {  // not unrolled: cold code
             const int j = SUB ? (i % (N / 2)) / 2 : i;

@@ -64,7 +64,7 @@ struct PowfTables {
 
 static const PowfTables kPowfTablesHost = {LH_POWF_LOG2_TAB, LH_POWF_EXP2_TAB};
 
-// The LDS copy the kernels use adds a "wide" log2 table: entry (k & 127) * 16 + i holds {invc[i], logc[i] + (double)k}
+// The LDS copy the kernels use adds a "wide" log2 table: entry (k & 127) * 16 + i holds {invc[i] * 2^-k, logc[i] + (double)k}
 // for the binary exponents k in [-64, 63] -- the two operands log2_inline needs, so that ONE 16-byte LDS read keyed by
 // bits 19..29 of (ix - OFF) replaces the 16-entry read, the arithmetic shift, the int -> double conversion and the fp64
 // add `logc + (double)k` (10 issue cycles per powf on gfx950; the sum is the same single rounding, done when the table
@@ -72,7 +72,7 @@ static const PowfTables kPowfTablesHost = {LH_POWF_LOG2_TAB, LH_POWF_EXP2_TAB};
 //
 // Round 6 adds the tables of the FOLDED form (powf_folded below) for the two powers whose arguments live in one narrow, fully
 // enumerable range -- PQdec's first power val^(1/m), val in [2^-21, 1], and PQenc's second power q^m, q in [0.7, 1.4):
-//   foldA[e] = {invc[i] * 2^21, (1/m) * (logc[i] + k)}   e = (k + 21) * 16 + i, k in [-21, 0]   (352 entries)
+//   foldA[e] = {invc[i] * 2^-k, (1/m) * (logc[i] + k)}   e = (k + 21) * 16 + i, k in [-21, 0]   (352 entries)
 //   foldC[i] = {invc[i],        m * logc[i]}              (k = 0 throughout)
 constexpr int FOLD_A_KMIN = -21, FOLD_A_LEN = (0 - FOLD_A_KMIN + 1) * 16;
 struct PowfTablesWide : PowfTables {
@@ -87,7 +87,10 @@ LH_HD void pw_wide_entry(int e, const double (&lt)[16][2], double &invc, double 
 {
     const int kk = e >> 4, i = e & 15;
     const int k = kk < 64 ? kk : kk - 128;
-    invc = lt[i][0];
+    // round 6: the reciprocal carries 2^-k, so that log2_inline's z = x 2^-k (an integer subtraction on the argument's exponent
+    // field and the mask that finds it: two instructions per powf) need not be formed at all -- r = fma(x, invc 2^-k, -1) is the
+    // same double as fma(z, invc, -1): both factors are scaled by exact powers of two, the product is the same real number
+    invc = __builtin_ldexp(lt[i][0], -k);
     y0 = lt[i][1] + (double)k;  // the one rounding of log2_inline's `logc + (double) k`
 }
 
@@ -226,15 +229,20 @@ LH_HD float powf_glibc(float x, float y, const Tab &T)
 }
 
 // log2_inline's table operands for tmp = ix - OFF: {invc, logc + (double)k}
-LH_HD void pw_log2_operands(const PowfTables &T, uint32_t tmp, double &invc, double &y0)
+// ... and z, the factor r = fma(z, invc, -1) is formed from: the argument with its exponent reduced (16-entry table) or the
+// argument itself (wide table, whose reciprocals carry the 2^-k)
+LH_HD void pw_log2_operands(const PowfTables &T, uint32_t ix, uint32_t tmp, double &invc, double &y0, double &z)
 {
     const int i = (tmp >> (23 - 4)) % 16;
-    const int k = (int32_t)(tmp & 0xff800000u) >> 23;
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int32_t)top >> 23;
     invc = T.log2_tab[i][0];
     y0 = T.log2_tab[i][1] + (double)k;
+    z = (double)pw_asfloat(ix - top);
 }
-LH_HD void pw_log2_operands(const PowfTablesWide &T, uint32_t tmp, double &invc, double &y0)
+LH_HD void pw_log2_operands(const PowfTablesWide &T, uint32_t ix, uint32_t tmp, double &invc, double &y0, double &z)
 {
+    z = (double)pw_asfloat(ix);
 #if defined(__HIP_DEVICE_COMPILE__)
     // v_bfe_u32, then one v_lshl_add_u32 forms the LDS address; written as a builtin or as shifts the compiler turns
     // it into shift + and + add (three instructions)
@@ -306,8 +314,15 @@ LH_HD float pw_exp2_tail(double rr, double s, bool zero)
 //   CHECK_E |y*log2(x)| may reach 126 (over/underflow handling of e_powf.c): raise `slow` then.  (1 / true: at 126; any other
 //           non-zero value: already at that bound -- a caller that wants the result's exponent inside a narrower range.)
 // powf_regular<true, true, true> accepts every argument and is what tests/test_gpu_exhaustive.py sweeps.
+// EMAX (round 6; wide table, ZERO, no CHECK_X): the |y log2 x| test as an INTEGER running maximum instead of a compare per call --
+// `emax` collects the high word of |ylogx| and the caller compares it once per unit with pw_emax_limit(bound).  A compare per
+// call keeps a lane mask alive per pixel and channel; with 24 of them in a unit the compiler ran out of scalar registers and
+// moved them through VGPRs as 0 / 1 (about twelve extra half-rate instructions per pixel in the decode kernel).  No `!zero`
+// term is needed: with the wide table an argument of +0 reads the entry of k = 1, i = 9 ({0.5, 1.0}), r = -1, and
+// |y log2| comes out as 2.29 y -- 14.4 for y = 1/n, far below every bound (tools/verify_powf.cpp asserts it).
+LH_HD uint32_t pw_emax_limit(int bound) { return (uint32_t)(pw_asuint64((double)bound) >> 47) << 15; }
 template <bool ZERO, bool CHECK_X, int CHECK_E, typename Tab>
-LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
+LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow, uint32_t *emax = nullptr)
 {
     const uint32_t ix = pw_asuint(x);
     bool zero = false;
@@ -318,11 +333,8 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
     const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
                  A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
     const uint32_t tmp = ix - 0x3f330000u;
-    const uint32_t top = tmp & 0xff800000u;
-    const uint32_t iz = ix - top;
-    double invc, y0;
-    pw_log2_operands(T, tmp, invc, y0);
-    const double z = (double)pw_asfloat(iz);
+    double invc, y0, z;
+    pw_log2_operands(T, ix, tmp, invc, y0, z);
     const double r = __builtin_fma(z, invc, -1.0);
     const double r2 = r * r;
     double yy = __builtin_fma(A0, r, A1);
@@ -336,6 +348,10 @@ LH_HD float powf_regular(float x, float y, const Tab &T, bool &slow)
         // the limit's top five mantissa bits are all the compare sees: 126 and 56 are exact in them
         const double lim = CHECK_E == 1 ? 126.0 : (double)CHECK_E;
         slow = slow || (!zero && ((pw_asuint64(ylogx) >> 47 & 0xffff) >= (pw_asuint64(lim) >> 47)));
+    }
+    if (emax) {
+        const uint32_t a = (uint32_t)(pw_asuint64(ylogx) >> 32) & 0x7fffffffu;
+        *emax = *emax > a ? *emax : a;
     }
     double rr, s;
     pw_exp2_split(ylogx, T, rr, s);
@@ -372,9 +388,8 @@ template <int WHICH>
 LH_HD void pw_fold_entry(int e, const double (&lt)[16][2], double &invc, double &y0)
 {
     const int i = e & 15, k = WHICH == 0 ? (e >> 4) + FOLD_A_KMIN : 0;
-    // WHICH 0: the argument's exponent field is raised by 21 before it is split (so that the table index starts at 0): z comes
-    // out scaled by 2^-21 and the reciprocal carries the 2^21 -- both exact, r = z invc - 1 is the same double
-    invc = WHICH == 0 ? lt[i][0] * 0x1p21 : lt[i][0];
+    // as in the wide table, the reciprocal carries 2^-k and the argument itself is the other factor of r = fma(x, invc 2^-k, -1)
+    invc = __builtin_ldexp(lt[i][0], -k);
     y0 = pw_fold_y<WHICH>() * (lt[i][1] + (double)k);
 }
 
@@ -388,8 +403,7 @@ LH_HD float powf_folded(float x, const PowfTablesWide &T)
     double invc, y0, z;
     if (WHICH == 0) {
         const uint32_t tmp = ix - (0x3f330000u + ((uint32_t)FOLD_A_KMIN << 23));   // (FOLD_A_KMIN < 0: the offset shrinks)
-        const uint32_t top = tmp & 0xff800000u;
-        z = (double)pw_asfloat(ix - top);                                           // z * 2^-21
+        z = (double)x;                                                              // (the table's reciprocals carry the 2^-k)
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t e;
         asm("v_bfe_u32 %0, %1, 19, 9" : "=v"(e) : "v"(tmp));

@@ -132,6 +132,17 @@ int main(int argc, char **argv)
             total += cnt;
         }
     }
+    // EMAX (pow_glibc.hpp): an argument of +0 must stay far below every bound on |y log2 x| (56 is the smallest in use) through
+    // the wide table for y = 1/n -- the decode kernels test that bound on a running maximum that +0 arguments take part in
+    for (int e = 3; e < 4; e++) {
+        bool slow = false;
+        uint32_t emax = 0;
+        const float r0 = lh::powf_regular<true, false, 0>(0.0f, ys[e], wide, slow, &emax);
+        if (r0 != 0.0f || slow || emax >= lh::pw_emax_limit(32)) {
+            fprintf(stderr, "MISMATCH (EMAX of +0) y=%a: result %a, high word of |ylogx| 0x%08x\n", ys[e], r0, emax);
+            total_bad++;
+        }
+    }
     printf("straight-line form applied to %llu (16-entry table) / %llu (wide table) of them\n",
            (unsigned long long)fast16.load(), (unsigned long long)fastw.load());
     printf("TOTAL %llu arguments, %llu mismatches\n", (unsigned long long)total, (unsigned long long)total_bad);
