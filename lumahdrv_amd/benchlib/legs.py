@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from .plan import BYTES_PER_PIXEL, CLOCK_GHZ, HBM_PEAK_GBS, N_SIMD, PACKED_RING, SEED, WORKLOADS, resident_frames, workload_text
+from .plan import BYTES_PER_PIXEL, READ_BYTES_PER_PIXEL, CLOCK_GHZ, HBM_PEAK_GBS, N_SIMD, PACKED_RING, SEED, WORKLOADS, resident_frames, workload_text
 from lumahdrv_amd.placement import CHUNK_BYTES
 
 from .resident import ResidentStream
@@ -228,6 +228,11 @@ def run_workload(L, args, name, w, h, B, K, Wm, rank, world, local_rank, use_dis
                                      if tr else "no PMC capture of the current kernel sources in profiles/ (null, not a stale figure)",
                    "traffic_only_ms": None if probe is None else round(probe, 4),
                    "frac_of_traffic_only_rate": None if probe is None else round(probe / (ms_ordered if ms_ordered else ms), 3)}
+            # north_star words its target as a fraction of the HBM-READ roofline: the bytes the launch READS (encode: the 12 B/pixel
+            # of float input, decode: the 3 B/pixel of planes) over the same durations and the same 8 TB/s
+            rb = READ_BYTES_PER_PIXEL[0 if "k_encode" in kern else 1] * px_step
+            blk["read_only"] = {"bytes_per_launch": rb, "frac": round(rb / ((ms_ordered if ms_ordered else ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "frac_overlapped": round(rb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return blk
 
         enc_blk = hbm_block(avg_ms, teo["dev_ms_median"] / K if teo else None, float(np.median(iso)), probe_ms,

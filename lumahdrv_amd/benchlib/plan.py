@@ -14,6 +14,7 @@ W4K, H4K = 3840, 2160
 W8K, H8K = 7680, 4320
 SEED = 20250929
 BYTES_PER_PIXEL = 15.0      # 12 B read (3 x fp32) + 3 B written (Y 2 B + U 0.5 B + V 0.5 B), SURVEY.md 8(d)
+READ_BYTES_PER_PIXEL = (12.0, 3.0)   # of those, what a launch READS: encode 3 x fp32, decode Y 2 B + U 0.5 B + V 0.5 B (profile 2)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_SIMD, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip-level parameters)
 PACKED_RING = 6             # batches of packed LumaFrames the packed-layout decode leg cycles through (6 x 20 x 4K = 12 GB)

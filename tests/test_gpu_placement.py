@@ -257,3 +257,49 @@ def test_library_allocated_decoded_ring_holds_the_packed_batch(oracle_mod):
             ring.close()
         ctx.set_stream(None)
         ctx.close()
+
+
+def test_small_pool_finds_groups_among_a_dozen_chunks_and_changes_no_byte(oracle_mod):
+    """lumahip_pool_create_small (round 6): the pool a caller that shares the GPU can afford -- it may take at most a dozen chunks for
+    its probes (not all free memory), keeps the 2 + 1 + 1 asked for and returns the rest; planes encoded into its chunks are the
+    bytes plain buffers get and frame 0 the oracle's.  Whether groups were found is reported, never assumed (a box without the
+    effect gives an ungrouped pool and the same bytes)."""
+    import torch
+    import lumahdrv_amd as L
+    from lumahdrv_amd.placement import CHUNK_BYTES, HbmChunkPool
+    o = oracle_mod
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    cfg = (L.PTF_PQ, 11, L.CS_LUV, 8, 1e4, 0.005)
+    ctx = L.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_quantizer(*cfg, L.build_lut(cfg[0], cfg[1], cfg[4], cfg[5]))
+    pool = HbmChunkPool(ctx, dev, 2, 1, 1, 0, small=True)
+    st_ = pool.stats
+    assert len(pool.float) == 2 and len(pool.y) == 1 and len(pool.uv) == 1
+    assert 4 <= st_["chunks"] <= 16                                   # probed: a dozen, not the ~140 the full pool takes
+    assert free0 - torch.cuda.mem_get_info(dev)[0] <= 5 * CHUNK_BYTES   # kept: the four chunks (+ allocator slack)
+    if st_.get("grouped"):
+        assert len(st_["groups"]) >= 2 and pool.group_of(pool.y[0]) != pool.group_of(pool.float[0])
+    w, h, B = 1920, 1080, 3
+    n3 = 3 * w * h
+    _, hs, stp, _ = L.plane_geometry(w, h, 2)
+    psz = [hs[p] * stp[p] for p in range(3)]
+    src = pool.float[0]
+    ctx.synth_frames_device(src.data_ptr(), n3, B, w, h, 21, 0)
+    placed = [pool.y[0].data_ptr(), pool.uv[0].data_ptr(), pool.uv[0].data_ptr() + (64 << 20)]
+    plain = [torch.zeros(B * psz[p], dtype=torch.uint8, device=dev) for p in range(3)]
+    ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, 1.0, 2, placed, stp, psz)
+    ctx.encode_frames_device(src.data_ptr(), n3, B, w, h, 1.0, 2, [t.data_ptr() for t in plain], stp, psz)
+    torch.cuda.synchronize()
+    for p in range(3):
+        got = placement_tensor(placed[p], B * psz[p], dev)
+        assert torch.equal(got, plain[p]), p
+    f0 = src[:n3 * 4].view(torch.float32).cpu().numpy().reshape(3, h, w)
+    exp, _, _ = o.Oracle(*cfg).encode(f0.copy(), 1.0, 2)
+    for p in range(3):
+        assert np.array_equal(plain[p][:psz[p]].cpu().numpy().reshape(hs[p], stp[p]), exp[p])
+    pool.close()
+    ctx.set_stream(None)
+    ctx.close()
