@@ -104,8 +104,18 @@ def test_bench_contract_single_gpu():
     bytes_ = rf["algorithmic_bytes_per_launch"]
     assert abs(bytes_ / (rf["kernel_ms_ordered"] * 1e-3) / 1e9 / rf["peak"] - rf["frac"]) < 2e-3 and rf["frac_overlapped"] > 0
     assert abs(bytes_ / (dr["kernel_ms_ordered"] * 1e-3) / 1e9 / dr["peak"] - dr["frac"]) < 2e-3
+    # round 6: the configuration is the arguments' (configs[1]: 500 frames resident, never fewer silently); the HBM-read wording of
+    # north_star beside the 15 B/pixel figures; the small pool and the plain allocations with their own ordered fractions
+    c = r["config"]
+    assert c["resident_frames"] == 500 and c["stream_frames"] == 500 and c["resident_frames_per_rank"] == [500] and r["config_degraded"] is False
+    ro, dro = rf["read_only"], dr["read_only"]
+    assert ro["bytes_per_launch"] == 12.0 * 20 * 3840 * 2160 and dro["bytes_per_launch"] == 3.0 * 20 * 3840 * 2160
+    assert abs(ro["frac"] / rf["frac"] - 0.8) < 1e-3 and abs(dro["frac"] / dr["frac"] - 0.2) < 1e-3
+    if "small_pool" in r:      # (absent only when a dozen chunks cannot be had)
+        sp = r["small_pool"]
+        assert sp["resident_frames"] == 40 and sp["value"] == r["value_small_pool"] > 0 and 0 < sp["frac_ordered"] < 1 and sp["pool_GB_kept"] < 10
     if r["placement"].get("grouped"):
-        assert r["value_placement_off"] > 0
+        assert r["value_placement_off"] > 0 and r["placement_off"]["resident_frames"] == 160 and 0 < r["placement_off"]["frac_ordered"] < 1
         # the reference's decoder returns the packed LumaFrame: that layout's decode rate, pool-placed and plainly allocated
         pk = r["decode_packed_layout"]
         # (a box with little free HBM gives the pool too few chunks for some of these legs: they are then absent, never wrong)
