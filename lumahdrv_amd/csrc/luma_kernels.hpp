@@ -727,6 +727,168 @@ LH_DEV void dec_load(DecUnit<SUB, VW> &u, const DecArgs &a, int t, int tx, int t
     }
 }
 
+// ---- the same loads as a REAL prefetch (round 6) ---------------------------------------------------------------------
+// dec_load unpacks every row right behind its load, so the compiler has to wait for each load (s_waitcnt vmcnt(0): the unit's
+// four loads are four serial round trips, each also waiting for every store issued before it) -- harmless where twenty waves per
+// CU hide it, but the YCbCr kernels run four waves per SIMD with microseconds of arithmetic per unit and spent most of a unit's
+// time in those waits.  DecRaw keeps the rows as loaded (six registers for 4:2:0 16-bit); dec_issue issues the loads of the NEXT
+// unit before the current unit is processed, and dec_finish unpacks them after the current unit's arithmetic and BEFORE its
+// stores (dec_process's hook): the one wait of an iteration then sits where only those loads and the previous unit's stores --
+// a whole unit's arithmetic old -- are outstanding, and this unit's stores are not waited for until the next one's arithmetic
+// is done.  (The compiler's waits are vmcnt(0) throughout: one counter for loads and stores on gfx950, and the conditional
+// stores of the loop defeat exact counting.)  Rows the vector loads cannot take (a.aligned == 0: odd strides of a
+// lossy upstream decoder) are loaded by dec_finish as dec_load does.
+template <bool SUB, int VW>
+struct DecRaw {
+    uint32_t y[2][2];
+    uint32_t c1[SUB ? 1 : 2][2], c2[SUB ? 1 : 2][2];
+    int f, ux, uy;
+    bool valid;
+};
+
+template <int N>
+LH_DEV void load_raw(const unsigned char *p, uint32_t (&r)[2], int bps)
+{
+    const int bytes = N * bps;   // 8, 4, 2 or 1; uniform
+    if (bytes == 8) {
+        const lh_v2u v = __builtin_nontemporal_load(reinterpret_cast<const lh_v2u *>(p));
+        r[0] = v.x;
+        r[1] = v.y;
+    } else if (bytes == 4) {
+        r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+    } else if (bytes == 2) {
+        r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(p));
+    } else {
+        r[0] = p[0];
+    }
+}
+
+template <int N>
+LH_DEV void unpack_raw(const uint32_t (&r)[2], int (&c)[N], int bps)
+{
+    if (bps == 2) {
+        if constexpr (N == 4) {
+            c[0] = r[0] & 0xffff; c[1] = r[0] >> 16; c[2] = r[1] & 0xffff; c[3] = r[1] >> 16;
+        } else if constexpr (N == 2) {
+            c[0] = r[0] & 0xffff; c[1] = r[0] >> 16;
+        } else {
+            c[0] = r[0] & 0xffff;
+        }
+    } else {
+        if constexpr (N == 4) {
+            c[0] = r[0] & 0xff; c[1] = (r[0] >> 8) & 0xff; c[2] = (r[0] >> 16) & 0xff; c[3] = r[0] >> 24;
+        } else if constexpr (N == 2) {
+            c[0] = r[0] & 0xff; c[1] = (r[0] >> 8) & 0xff;
+        } else {
+            c[0] = r[0] & 0xff;
+        }
+    }
+}
+
+template <bool SUB, int VW>
+LH_DEV void dec_issue(DecRaw<SUB, VW> &u, const DecArgs &a, int t, int tx, int ty, int NW)
+{
+    u.valid = false;
+    if (t >= a.g.totalTiles)
+        return;
+    int bx, by;
+    tile_coords(t, a.g, u.f, bx, by);
+    u.ux = bx * 64 + tx;
+    u.uy = by * NW + ty;
+    if (u.ux >= a.g.unitsX || u.uy >= a.g.unitsY)
+        return;
+    u.valid = true;
+    if (!a.aligned)
+        return;   // (dec_finish loads these rows itself)
+    const int f = u.f, ux = u.ux, uy = u.uy;
+    const unsigned char *s = a.src[0] + (size_t)f * a.src_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * VW * a.bps;
+    load_raw<VW>(s, u.y[0], a.bps);
+    load_raw<VW>(s + a.stride[0], u.y[1], a.bps);
+    if constexpr (SUB) {
+        constexpr int NQ = VW / 2;
+        load_raw<NQ>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * NQ * a.bps, u.c1[0], a.bps);
+        load_raw<NQ>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * NQ * a.bps, u.c2[0], a.bps);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            load_raw<VW>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)(2 * uy + r) * a.stride[1] + (size_t)ux * VW * a.bps, u.c1[r], a.bps);
+            load_raw<VW>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)(2 * uy + r) * a.stride[2] + (size_t)ux * VW * a.bps, u.c2[r], a.bps);
+        }
+    }
+}
+
+template <bool SUB, int VW>
+LH_DEV void dec_finish(DecUnit<SUB, VW> &u, const DecRaw<SUB, VW> &w, const DecArgs &a)
+{
+    u.f = w.f;
+    u.ux = w.ux;
+    u.uy = w.uy;
+    u.valid = w.valid;
+    if (!w.valid)
+        return;
+    if (a.aligned) {
+        unpack_raw<VW>(w.y[0], u.y[0], a.bps);
+        unpack_raw<VW>(w.y[1], u.y[1], a.bps);
+        if constexpr (SUB) {
+            unpack_raw<VW / 2>(w.c1[0], u.c1, a.bps);
+            unpack_raw<VW / 2>(w.c2[0], u.c2, a.bps);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int row[VW];
+                unpack_raw<VW>(w.c1[r], row, a.bps);
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    u.c1[r * VW + i] = row[i];
+                unpack_raw<VW>(w.c2[r], row, a.bps);
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    u.c2[r * VW + i] = row[i];
+            }
+        }
+        return;
+    }
+    const int f = u.f, ux = u.ux, uy = u.uy;
+    const unsigned char *s = a.src[0] + (size_t)f * a.src_frame_stride[0] + (size_t)(2 * uy) * a.stride[0] + (size_t)ux * VW * a.bps;
+    load_samples<VW>(s, u.y[0], a.bps, 0);
+    load_samples<VW>(s + a.stride[0], u.y[1], a.bps, 0);
+    if constexpr (SUB) {
+        constexpr int NQ = VW / 2;
+        load_samples<NQ>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)uy * a.stride[1] + (size_t)ux * NQ * a.bps, u.c1, a.bps, 0);
+        load_samples<NQ>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)uy * a.stride[2] + (size_t)ux * NQ * a.bps, u.c2, a.bps, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            int row[VW];
+            load_samples<VW>(a.src[1] + (size_t)f * a.src_frame_stride[1] + (size_t)(2 * uy + r) * a.stride[1] + (size_t)ux * VW * a.bps, row, a.bps, 0);
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                u.c1[r * VW + i] = row[i];
+            load_samples<VW>(a.src[2] + (size_t)f * a.src_frame_stride[2] + (size_t)(2 * uy + r) * a.stride[2] + (size_t)ux * VW * a.bps, row, a.bps, 0);
+#pragma unroll
+            for (int i = 0; i < VW; i++)
+                u.c2[r * VW + i] = row[i];
+        }
+    }
+}
+
+// the unit's samples must be in registers HERE (the compiler may not sink the unpacking, and with it the wait for the loads,
+// below the stores that follow)
+template <bool SUB, int VW>
+LH_DEV void dec_pin(DecUnit<SUB, VW> &u)
+{
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < VW; i++)
+            asm volatile("" : "+v"(u.y[r][i]));
+#pragma unroll
+    for (int j = 0; j < (SUB ? VW / 2 : 2 * VW); j++) {
+        asm volatile("" : "+v"(u.c1[j]));
+        asm volatile("" : "+v"(u.c2[j]));
+    }
+}
+
 // Whether this wave reads red and blue of the current unit from the per-stream tables (k_decode<..., RB>) or computes them.
 // What a gather costs is decided by the CU's 32 KiB vector L1 (profiles/r05_ycbcr_decode_tables.txt, TCP_TCC_READ_REQ): a
 // table line holds 32 consecutive luminance codes of ONE colour code; with the codes of a picture a lane's eight pixels read
@@ -771,8 +933,14 @@ LH_DEV bool rb_wave_local(const DecUnit<SUB, VW> &u, int near_y, int near_c)
 
 // SCFAST (YCbCr): the straight-line code divides by sc with the short division (XformConst::sc_mode == 1, ycbcr_inv_n)
 // Returns (RB only; wave-uniform) whether the wave took red and blue of this unit from the tables.
-template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, bool SCFAST = false, bool RB = false, typename LutPtr, typename K>
-LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k, LutPtr lut, const float *s_uv)
+// before_stores: called once between the unit's arithmetic and its stores (the prefetching loop of k_decode completes the NEXT
+// unit's loads there)
+struct DecNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int CS, bool SUB, int VW, bool DISP, bool UVTAB, bool YT = false, bool SCFAST = false, bool RB = false, typename LutPtr, typename K,
+          typename Hook = DecNoHook>
+LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k, LutPtr lut, const float *s_uv, Hook before_stores = Hook())
 {
     bool gathered = false;
     static_assert(!RB || (YT && CS == CS_YCBCR), "the red / blue tables belong to the YCbCr kernels with the y table");
@@ -906,6 +1074,7 @@ LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k,
                     out[c][r][i] = div_ieee(out[c][r][i], k.sc);
     }
 
+    before_stores();
     if (!DISP || a.dst[0]) {
         const size_t px = (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
         if (a.rot_on) {   // (kernel argument: uniform; u.f is wave-uniform, so the base is a scalar select)
@@ -994,35 +1163,55 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     const int G = gridDim.x;
 
     bool any_gather = false;
+#ifndef LH_DEC_PF
+#define LH_DEC_PF 1
+#endif
+    // PF: the real prefetch of DecRaw -- the kernels with microseconds of arithmetic per unit and four waves per SIMD (YCbCr)
+    constexpr bool PF = LH_DEC_PF == 2 || (LH_DEC_PF == 1 && CS == CS_YCBCR);
     DecUnit<SUB, VW> cur, nxt;
-    dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
+    DecRaw<SUB, VW> nxt_w;
+    if constexpr (PF) {
+        dec_issue<SUB, VW>(nxt_w, a, blockIdx.x, tx, ty, NW);
+        dec_finish<SUB, VW>(cur, nxt_w, a);
+    } else {
+        dec_load<SUB, VW>(cur, a, blockIdx.x, tx, ty, NW);
+    }
     for (int t = blockIdx.x; t < a.g.totalTiles; t += G) {
+        if constexpr (PF)
+            dec_issue<SUB, VW>(nxt_w, a, t + G, tx, ty, NW);
+        auto hook = [&]() {
+            if constexpr (PF) {
+                dec_finish<SUB, VW>(nxt, nxt_w, a);
+                if (nxt.valid)
+                    dec_pin<SUB, VW>(nxt);
+            }
+        };
         if (cur.valid) {
             if constexpr (CS == CS_YCBCR) {
                 // two copies of the unit's code, chosen by a kernel argument: see ycbcr_inv_n on why not a run-time choice inside
                 if (k.sc_mode == 1) {
                     if constexpr (GL)
-                        dec_process<CS, SUB, VW, DISP, false, false, true>(cur, a, k, a.q.lut, s_uv);
+                        dec_process<CS, SUB, VW, DISP, false, false, true>(cur, a, k, a.q.lut, s_uv, hook);
                     else
-                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, true, RB>(cur, a, k, s_lut, s_uv);
+                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, true, RB>(cur, a, k, s_lut, s_uv, hook);
                 } else {
                     if constexpr (GL)
-                        dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
+                        dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv, hook);
                     else
-                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, false, RB>(cur, a, k, s_lut, s_uv);
+                        any_gather |= dec_process<CS, SUB, VW, DISP, UVTAB, YT, false, RB>(cur, a, k, s_lut, s_uv, hook);
                 }
             } else if constexpr (GL) {
-                dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv);
+                dec_process<CS, SUB, VW, DISP, false>(cur, a, k, a.q.lut, s_uv, hook);
             } else {
-                dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv);
+                dec_process<CS, SUB, VW, DISP, UVTAB, YT>(cur, a, k, s_lut, s_uv, hook);
             }
+        } else {
+            hook();
         }
-        // the next unit's sample loads go out AFTER this unit's stores (as in k_encode): neutral for 4:2:0, +17 % for the
-        // write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B)
-        // (round 5, YCbCr: issuing these loads BEFORE the unit is processed, so that its powf chains cover their latency, is not
-        // faster -- 812 against 821 us per 20 x 4K with four pixels per thread, where it spills 17 VGPRs, and 938 against 798 with
-        // two: the waves do not wait for these loads, profiles/r05_ycbcr_decode_tables.txt)
-        dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
+        // Without PF (the HBM-bound colour spaces): the next unit's sample loads go out AFTER this unit's stores (as in k_encode):
+        // neutral for 4:2:0, +17 % for the write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B).
+        if constexpr (!PF)
+            dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
         cur = nxt;
     }
     if constexpr (RB) {
