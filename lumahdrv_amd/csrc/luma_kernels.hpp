@@ -1167,10 +1167,23 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
 #define LH_DEC_PF 1
 #endif
     // PF: the real prefetch of DecRaw -- the kernels with microseconds of arithmetic per unit and four waves per SIMD (YCbCr)
-    constexpr bool PF = LH_DEC_PF == 2 || (LH_DEC_PF == 1 && CS == CS_YCBCR);
+    // How the next unit's rows are loaded (same-box A/B per kernel family, profiles/r06_decode_prefetch.txt):
+    //   PFM 1  raw loads BEFORE this unit is processed, unpacked between its arithmetic and its stores (DecRaw above): the YCbCr
+    //          kernels (-2.5 % on unrelated pixels, +5 % on pictures) and every 4:4:4 kernel (six row loads per unit that used to be
+    //          six serial round trips: -10 ... -17 %);
+    //   PFM 2  raw loads AFTER this unit's stores, unpacked at the top of the next iteration: the four loads go out back to back
+    //          instead of one round trip each, in the order (stores, then loads) of the HBM-bound kernels: the HBM-bound
+    //          4:2:0 kernels with 8-bit samples (-5 %);
+    //   PFM 0  dec_load as before round 6: the HBM-bound 4:2:0 kernels with 16-BIT samples (BASELINE's profile 2), where either
+    //          form above is 4 - 6 % SLOWER -- four loads in flight per wave instead of one round trip after another is more
+    //          concurrency than that traffic mix likes (the same finding as "5 workgroups per CU, not 8", lumahip_launch.hip).
+    // The 4:2:0 kernels of the HBM-bound colour spaces therefore carry both loops and pick by the sample size (a kernel argument).
+    auto run = [&](auto pfm_tag) {
+    constexpr int PFM = decltype(pfm_tag)::value;
+    constexpr bool PF = PFM == 1;
     DecUnit<SUB, VW> cur, nxt;
     DecRaw<SUB, VW> nxt_w;
-    if constexpr (PF) {
+    if constexpr (PFM != 0) {
         dec_issue<SUB, VW>(nxt_w, a, blockIdx.x, tx, ty, NW);
         dec_finish<SUB, VW>(cur, nxt_w, a);
     } else {
@@ -1208,12 +1221,23 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         } else {
             hook();
         }
-        // Without PF (the HBM-bound colour spaces): the next unit's sample loads go out AFTER this unit's stores (as in k_encode):
-        // neutral for 4:2:0, +17 % for the write-heavy 4:4:4 variants (252 -> 294 Gpixel/s, same-box A/B).
-        if constexpr (!PF)
+        if constexpr (PFM == 2) {
+            dec_issue<SUB, VW>(nxt_w, a, t + G, tx, ty, NW);
+            dec_finish<SUB, VW>(nxt, nxt_w, a);   // (nothing between the loads depends on them: the waits sit here, behind all of them)
+        } else if constexpr (PFM == 0) {
             dec_load<SUB, VW>(nxt, a, t + G, tx, ty, NW);
+        }
         cur = nxt;
     }
+    };   // run
+    if constexpr (LH_DEC_PF == 0)
+        run(std::integral_constant<int, 0>());
+    else if constexpr (CS == CS_YCBCR || !SUB)
+        run(std::integral_constant<int, 1>());
+    else if (a.bps == 1)
+        run(std::integral_constant<int, 2>());
+    else
+        run(std::integral_constant<int, 0>());
     if constexpr (RB) {
         if (a.rb_flag) {   // (kernel argument: uniform)
             if (any_gather)
