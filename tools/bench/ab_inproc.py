@@ -38,10 +38,10 @@ def main():
     direction = int(os.environ.get("AB_DIRECTION", "0"))   # 0 encode, 1 decode
     mods = [load(a_path, "capi_a"), load(b_path, "capi_b")]
     cfgs = {"pq11_luv": (1, 11, 0, 8, 1e4, 0.005, 1.0), "pq10_ycbcr": (1, 10, 2, 10, 1000.0, 0.01, 20.0),
-            "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0), "pq11_rgb": (1, 11, 1, 8, 1e4, 0.005, 1.0),
+            "log12_luv": (2, 12, 0, 8, 1e4, 0.005, 1.0), "pq11_rgb": (1, 11, 1, 8, 1e4, 0.005, 1.0), "pq13_luv": (1, 13, 0, 8, 1e4, 0.005, 1.0),
             "pq8_luv": (1, 8, 0, 8, 1e4, 0.005, 1.0)}
     ptf, bits, cs, bitsC, mx, mn, sc = cfgs[wl]
-    w, h, B, nb, profile = 3840, 2160, 20, int(os.environ.get("AB_BATCHES", "25")), int(os.environ.get("AB_PROFILE", "2"))
+    w, h, B, nb, profile = 3840, 2160, int(os.environ.get("AB_FRAMES", "20")), int(os.environ.get("AB_BATCHES", "25")), int(os.environ.get("AB_PROFILE", "2"))
     n3 = 3 * w * h
     dev = torch.device("cuda:0")
     _, hs, st, _ = mods[0].plane_geometry(w, h, profile)
