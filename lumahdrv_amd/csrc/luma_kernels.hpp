@@ -1078,7 +1078,12 @@ LH_DEV bool dec_process(const DecUnit<SUB, VW> &u, const DecArgs &a, const K &k,
     if (!DISP || a.dst[0]) {
         const size_t px = (size_t)(2 * u.uy) * a.g.w + (size_t)u.ux * VW;
         if (a.rot_on) {   // (kernel argument: uniform; u.f is wave-uniform, so the base is a scalar select)
-            const int k = u.f / 3, j = u.f - 3 * k;
+            // (readfirstlane: the frame index IS wave-uniform, and saying so keeps the choice among the three bases a scalar one.
+            //  Without it the compiler -- once `a` is reachable through the loop's lambdas -- reads a.rot[j] with a VECTOR load from
+            //  the kernel arguments and waits for it with vmcnt(0) right in front of the stores, i.e. for every store of the
+            //  previous unit: 0.744 -> 0.683 of the roofline on this path, found in two default bench runs.)
+            const int fu = __builtin_amdgcn_readfirstlane(u.f);
+            const int k = fu / 3, j = fu - 3 * k;
             float *base = (j == 0 ? a.rot[0] : j == 1 ? a.rot[1] : a.rot[2]) + (size_t)k * a.frame_stride + px;
             const size_t n1 = (size_t)a.g.w * a.g.h;
 #pragma unroll
@@ -1172,12 +1177,16 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
     //          kernels (-2.5 % on unrelated pixels, +5 % on pictures) and every 4:4:4 kernel (six row loads per unit that used to be
     //          six serial round trips: -10 ... -17 %);
     //   PFM 2  raw loads AFTER this unit's stores, unpacked at the top of the next iteration: the four loads go out back to back
-    //          instead of one round trip each, in the order (stores, then loads) of the HBM-bound kernels: the HBM-bound
-    //          4:2:0 kernels with 8-bit samples (-5 %);
+    //          instead of one round trip each, in the order (stores, then loads) of the HBM-bound kernels: good for the HBM-bound
+    //          4:2:0 kernels with 8-bit samples (-5 %), bad for 16-bit ones (below); not instantiated by default;
     //   PFM 0  dec_load as before round 6: the HBM-bound 4:2:0 kernels with 16-BIT samples (BASELINE's profile 2), where either
     //          form above is 4 - 6 % SLOWER -- four loads in flight per wave instead of one round trip after another is more
     //          concurrency than that traffic mix likes (the same finding as "5 workgroups per CU, not 8", lumahip_launch.hip).
-    // The 4:2:0 kernels of the HBM-bound colour spaces therefore carry both loops and pick by the sample size (a kernel argument).
+    // The 4:2:0 kernels of the HBM-bound colour spaces keep PFM 0 for both sample sizes (carrying both loops and picking by the
+    // sample size at run time gave 8-bit 4:2:0 -3.6 % and cost the 13-bit tables +1 %: not worth a second loop in BASELINE's kernel).
+#ifndef LH_DEC_PFM_SUB
+#define LH_DEC_PFM_SUB 0
+#endif
     auto run = [&](auto pfm_tag) {
     constexpr int PFM = decltype(pfm_tag)::value;
     constexpr bool PF = PFM == 1;
@@ -1234,10 +1243,8 @@ __global__ __launch_bounds__(1024) void k_decode(const DecArgs a)
         run(std::integral_constant<int, 0>());
     else if constexpr (CS == CS_YCBCR || !SUB)
         run(std::integral_constant<int, 1>());
-    else if (a.bps == 1)
-        run(std::integral_constant<int, 2>());
     else
-        run(std::integral_constant<int, 0>());
+        run(std::integral_constant<int, LH_DEC_PFM_SUB>());
     if constexpr (RB) {
         if (a.rb_flag) {   // (kernel argument: uniform)
             if (any_gather)
